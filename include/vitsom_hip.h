@@ -1,0 +1,170 @@
+/* libvitsom_hip.so -- C-ABI of the MI355X-native ViT-SOM training-step kernels (gfx950 only).
+ *
+ * The reference (aluo7/ViT-SOM) is pure Python and has NO FFI/plugin interface;
+ * each entry point below replaces the torch/ATen op sequence at the cited reference lines
+ * (paths relative to the reference repo root).  A maintainer binds them with ctypes
+ * (see INTEGRATION.md); the build's own host mirror lives in vit-som_amd/.
+ *
+ * Conventions (every entry):
+ *   - returns 0 (VSOM_OK) on success, a negative VSOM_E* for a rejected call (bad shape,
+ *     alignment, unsupported configuration, short workspace) or a positive hipError_t;
+ *     vsom_last_error_string() describes the last failure on the calling thread;
+ *   - all pointers are DEVICE pointers owned by the caller, fp32 row-major unless stated;
+ *     BMU indices and labels are int64; "ld*" are row strides in ELEMENTS;
+ *   - no allocation, no host synchronisation, no exceptions; work is enqueued on `stream`;
+ *   - scratch is caller-supplied, sized by the matching *_workspace_bytes() query.
+ */
+#ifndef VITSOM_HIP_H
+#define VITSOM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* vsom_stream_t; /* == hipStream_t */
+
+#define VSOM_OK 0
+#define VSOM_EINVAL (-1)       /* null pointer / non-positive or inconsistent shape */
+#define VSOM_EALIGN (-2)       /* pointer or leading dimension not 16-byte aligned where required */
+#define VSOM_EUNSUPPORTED (-3) /* configuration outside what the kernels implement */
+#define VSOM_EWORKSPACE (-4)   /* workspace pointer null or too small */
+
+#define VSOM_VERSION 100
+
+int vsom_version(void);
+const char* vsom_last_error_string(void);
+
+/* ------------------------------------------------------------------ Linear layers (f32 MFMA) */
+/* Y[M,N] = X[M,K] * W[N,K]^T + bias      -- nn.Linear forward: qkv models/vit.py:30,
+ * decoder_pred vit.py:234, cls_head models/vit_som.py:77.  bias may be NULL. */
+int vsom_linear_fwd(const float* X, long ldx, const float* W, const float* bias, float* Y, long ldy,
+                    int M, int N, int K, vsom_stream_t stream);
+
+/* Ypre = X*W^T + bias ; Yact = gelu_erf(Ypre)   -- mlp.0 + nn.GELU(), vit.py:53-54.
+ * Both outputs dense [M,N]. */
+int vsom_linear_gelu_fwd(const float* X, long ldx, const float* W, const float* bias, float* Ypre,
+                         float* Yact, int M, int N, int K, vsom_stream_t stream);
+
+/* Y[m] = X[m]*W^T + bias + R[m % r_mod]   -- Linear + residual add (attn.proj vit.py:38,61;
+ * mlp.2 vit.py:55,62: r_mod = M, R = block input) and Linear + broadcast table
+ * (decoder_embed + decoder_pos_embed vit.py:225-226: r_mod = tokens per image). */
+int vsom_linear_residual_fwd(const float* X, long ldx, const float* W, const float* bias,
+                             const float* R, long ldr, int r_mod, float* Y, long ldy, int M, int N,
+                             int K, vsom_stream_t stream);
+
+/* dX[M,K] (+)= dY[M,N] * W[N,K]  (optionally  .* gelu_erf'(gelu_pre[M,K]) )
+ * -- autograd of nn.Linear w.r.t. its input (and of nn.GELU when gelu_pre != NULL, dense [M,K]). */
+int vsom_linear_bwd_input(const float* dY, long lddy, const float* W, float* dX, long lddx, int M,
+                          int N, int K, int accumulate, const float* gelu_pre, vsom_stream_t stream);
+
+/* dW[N,K] = dY[M,N]^T * X[M,K] ;  db[N] = column sums of dY (db may be NULL)
+ * -- autograd of nn.Linear w.r.t. weight/bias.  The reduction over the M token rows is split
+ * across workgroups into fp32 slabs in `ws` and summed in a fixed order (deterministic). */
+size_t vsom_linear_bwd_weight_workspace_bytes(int M, int N, int K);
+int vsom_linear_bwd_weight(const float* dY, long lddy, const float* X, long ldx, float* dW, float* db,
+                           int M, int N, int K, void* ws, size_t ws_bytes, vsom_stream_t stream);
+
+/* ------------------------------------------------------------------ patch embedding */
+/* tokens[B, n+1, E]: row 0 = cls_token + pos[0]; row 1+i = Conv2d(k=s=p)(img)[patch i] + bias + pos[1+i]
+ * -- timm PatchEmbed + vit.py:207-212.  img [B,C,S,S]; Wpe [E, C*p*p] (= conv weight [E,C,p,p]);
+ * pos [n+1, E]; xp_ws [B*n, C*p*p] scratch that the backward re-uses (gathered patches). */
+int vsom_patch_embed_fwd(const float* img, const float* Wpe, const float* bpe, const float* pos,
+                         const float* cls_token, float* tokens, float* xp_ws, int B, int C, int S,
+                         int p, int E, vsom_stream_t stream);
+size_t vsom_patch_embed_bwd_workspace_bytes(int B, int C, int S, int p, int E);
+/* dWpe, dbpe, dcls_token[E] from dtokens[B, n+1, E] (autograd of the above; pos is frozen). */
+int vsom_patch_embed_bwd(const float* dtokens, const float* xp_ws, float* dWpe, float* dbpe,
+                         float* dcls_token, int B, int C, int S, int p, int E, void* ws,
+                         size_t ws_bytes, vsom_stream_t stream);
+
+/* ------------------------------------------------------------------ LayerNorm */
+/* Y = (X - mean)/sqrt(var + eps) * gamma + beta, rows x cols; saves mean/rstd per row.
+ * -- nn.LayerNorm(eps=1e-6): vit.py:48,50,85,95 (eps from vit_som.py:50). cols <= 1024. */
+int vsom_layernorm_fwd(const float* X, const float* gamma, const float* beta, float* Y, float* mean,
+                       float* rstd, int rows, int cols, float eps, vsom_stream_t stream);
+size_t vsom_layernorm_bwd_workspace_bytes(int rows, int cols);
+/* dX = (resid ? resid : 0) + LN'(dY);  dgamma, dbeta = column reductions (deterministic). */
+int vsom_layernorm_bwd(const float* dY, const float* X, const float* mean, const float* rstd,
+                       const float* gamma, const float* resid, float* dX, float* dgamma, float* dbeta,
+                       int rows, int cols, void* ws, size_t ws_bytes, vsom_stream_t stream);
+
+/* ------------------------------------------------------------------ multi-head attention */
+/* out[B,N,H*hd] = softmax(q k^T * hd^-0.5) v, qkv laid out [B,N,3,H,hd] (the qkv Linear's
+ * output, vit.py:30-37; dropout p=0).  lse[B,H,N] = log-sum-exp of the scaled scores (saved for
+ * the backward, which recomputes the probabilities). */
+int vsom_attention_fwd(const float* qkv, float* out, float* lse, int B, int N, int H, int hd,
+                       vsom_stream_t stream);
+/* dqkv[B,N,3,H,hd] from dout[B,N,H*hd] (autograd of the above). delta_ws: [B,H,N] floats. */
+int vsom_attention_bwd(const float* qkv, const float* out, const float* dout, const float* lse,
+                       float* dqkv, float* delta_ws, int B, int N, int H, int hd,
+                       vsom_stream_t stream);
+
+/* ------------------------------------------------------------------ SOM layer */
+/* inv_norm[r] = 1 / max(||X[r,:]||_2, eps)   -- F.normalize(p=2, eps=1e-12), som_layer.py:120-121 */
+int vsom_row_inv_norm(const float* X, long ldx, int rows, int cols, float eps, float* inv_norm,
+                      vsom_stream_t stream);
+/* Best-matching-unit search, cosine: dist[B,K] = 1 - (X/|X|)(W/|W|)^T ; bmu[b] = first argmin_k
+ * -- SOMLayer.compute_distances + forward, som_layer.py:83-89,119-122.  X [B,L] (row stride ldx:
+ * the patch tokens of image b are contiguous), W [K,L] dense.  dist may be NULL. */
+size_t vsom_bmu_cosine_workspace_bytes(int B, int K, int L);
+int vsom_bmu_cosine_fwd(const float* X, long ldx, const float* W, const float* inv_nx,
+                        const float* inv_nw, float* dist, int64_t* bmu, int B, int K, int L, void* ws,
+                        size_t ws_bytes, vsom_stream_t stream);
+/* Neighbourhood weights + SOM loss + backward coefficients in one pass over [B,K]:
+ *   h_ik = exp(-||g_k - g_bmu(i)||^2 / (2 T^2))              compute_weights, som_layer.py:144-152
+ *   loss_sum[0] = sum_ik h_ik d_ik   (caller divides by B*K)  som_loss, som_layer.py:137-142
+ *   (all loss sums are two-stage fixed-order reductions: bitwise reproducible)
+ *   coef[i,k] = -c * h_ik * inv_nx[i] * inv_nw[k],  c = grad_scale
+ *   row_dot[i] = c * inv_nx[i]^2 * sum_k h_ik (1 - d_ik);  col_dot[k] likewise over i
+ * h may be NULL; coef/row_dot/col_dot may all be NULL (forward only).  grid [K,2] float. */
+size_t vsom_som_neigh_workspace_bytes(int B, int K);
+int vsom_som_neigh_loss(const float* dist, const int64_t* bmu, const float* grid, float T,
+                        const float* inv_nx, const float* inv_nw, float grad_scale, float* h,
+                        float* loss_sum, float* coef, float* row_dot, float* col_dot, int B, int K,
+                        void* ws, size_t ws_bytes, vsom_stream_t stream);
+/* Prototype gradient ("per-BMU neighbourhood accumulator") and input gradient of
+ * gamma_t * mean(h * d) through both F.normalize calls:
+ *   gW[K,L]  = coef^T X + col_dot[k] * W[k,:]
+ *   gX[B,L] += coef  W + row_dot[i] * X[i,:]        (accumulated into the token gradient) */
+int vsom_som_bwd(const float* X, long ldx, const float* W, const float* coef, const float* row_dot,
+                 const float* col_dot, float* gW, float* gX, long ldgx, int accumulate_gx, int B, int K,
+                 int L, vsom_stream_t stream);
+
+/* ------------------------------------------------------------------ losses */
+/* L1Loss(unpatchify(pred[:,1:,:]), img) -- vit.py:141-153,234-236 + vit_som.py:100.
+ * pred [B, n+1, p*p*C] (row 0 of each image = CLS prediction, ignored); img [B,C,S,S].
+ * recon [B,C,S,S] (may be NULL); loss_sum[0] = sum |recon-img| (caller divides by B*C*S*S);
+ * dpred (may be NULL) = grad_scale * sign(recon-img) in pred layout, CLS rows zero. */
+size_t vsom_l1_unpatchify_workspace_bytes(int B, int C, int S, int p);
+int vsom_l1_unpatchify(const float* pred, const float* img, float* recon, float* loss_sum,
+                       float* dpred, float grad_scale, int B, int C, int S, int p, void* ws,
+                       size_t ws_bytes, vsom_stream_t stream);
+/* CrossEntropyLoss(label_smoothing=s)(logits[B,C], y[B]) -- vit_som.py:62,96.
+ * loss_sum[0] = sum_b loss_b (caller divides by B); dlogits (may be NULL) = grad_scale * dloss_b/dlogits. */
+size_t vsom_cross_entropy_ls_workspace_bytes(int B);
+int vsom_cross_entropy_ls(const float* logits, const int64_t* y, float smoothing, float* loss_sum,
+                          float* dlogits, float grad_scale, int B, int C, void* ws, size_t ws_bytes,
+                          vsom_stream_t stream);
+
+/* ------------------------------------------------------------------ optimiser */
+/* One decoupled-weight-decay Adam step over a flat fp32 arena (torch.optim.AdamW semantics,
+ * vit_som.py:146-151).  wd_per_chunk[i] is the weight decay of elements [256 i, 256 i + 256);
+ * adamw=0 selects torch.optim.Adam (L2 in the gradient).  g is multiplied by grad_scale first
+ * (1/world_size after a sum all-reduce). */
+int vsom_adamw_step(float* p, const float* g, float* m, float* v, const float* wd_per_chunk, long n,
+                    float lr, float beta1, float beta2, float eps, int step, float grad_scale,
+                    int adamw, vsom_stream_t stream);
+
+/* ------------------------------------------------------------------ small utilities */
+int vsom_fill(float* p, long n, float value, vsom_stream_t stream);
+/* out[j] = sum_s slabs[s*stride + j], j in [0,n) -- fixed summation order */
+int vsom_reduce_slabs(const float* slabs, long stride, int nslabs, float* out, long n,
+                      vsom_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VITSOM_HIP_H */

@@ -1,0 +1,350 @@
+"""GPU parity tests, one C-ABI entry at a time, against the CPU oracle / torch fp32 (fp64 where
+summation order matters).  Tolerances are stated per test; index outputs are exact."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import rel_err
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from vit_som_amd import ops as _ops
+    return _ops
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import vitsom_oracle
+    return vitsom_oracle
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def dev(t):
+    return t.to(DEV)
+
+
+# fp32 GEMM tolerance: relative Frobenius error vs an fp64 reference
+GEMM_TOL = 2e-6
+
+
+@pytest.mark.parametrize("M,N,K,ldpad", [(70, 50, 48, 0), (300, 192, 192, 0), (257, 576, 192, 8), (33, 10, 24, 0),
+                                          (130, 96, 4, 0), (64, 768, 192, 0), (5, 3, 2, 0), (128, 128, 33, 3)])
+def test_linear_fwd(ops, M, N, K, ldpad):
+    xfull = rnd(M, K + ldpad, seed=1)
+    x = xfull[:, :K]
+    W, b = rnd(N, K, seed=2, scale=0.1), rnd(N, seed=3)
+    ref = (x.double() @ W.double().T + b.double())
+    xd = dev(xfull)[:, :K]
+    out = torch.empty(M, N, device=DEV)
+    ops.linear_fwd(xd, dev(W), dev(b), out)
+    assert rel_err(out.cpu(), ref) < GEMM_TOL
+    out2 = torch.empty(M, N, device=DEV)
+    ops.linear_fwd(xd, dev(W), None, out2)
+    assert rel_err(out2.cpu(), ref - b.double()) < GEMM_TOL
+
+
+@pytest.mark.parametrize("M,N,K", [(130, 768, 192), (37, 64, 16), (70, 16, 4)])
+def test_linear_gelu_fwd(ops, M, N, K):
+    x, W, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.2), rnd(N, seed=3)
+    pre_ref = x.double() @ W.double().T + b.double()
+    act_ref = F.gelu(pre_ref)
+    pre, act = torch.empty(M, N, device=DEV), torch.empty(M, N, device=DEV)
+    ops.linear_gelu_fwd(dev(x), dev(W), dev(b), pre, act)
+    assert rel_err(pre.cpu(), pre_ref) < GEMM_TOL
+    assert rel_err(act.cpu(), act_ref) < 5e-6
+
+
+@pytest.mark.parametrize("M,N,K,rmod", [(130, 192, 768, 130), (130, 96, 192, 65), (68, 4, 16, 17)])
+def test_linear_residual_fwd(ops, M, N, K, rmod):
+    x, W, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.1), rnd(N, seed=3)
+    R = rnd(rmod, N, seed=4)
+    ref = x.double() @ W.double().T + b.double() + R.double().repeat(M // rmod, 1)
+    out = torch.empty(M, N, device=DEV)
+    ops.linear_residual_fwd(dev(x), dev(W), dev(b), dev(R), rmod, out)
+    assert rel_err(out.cpu(), ref) < GEMM_TOL
+
+
+@pytest.mark.parametrize("M,N,K", [(130, 576, 192), (257, 192, 768), (33, 10, 24), (70, 12, 4), (300, 768, 192)])
+def test_linear_bwd_input(ops, M, N, K):
+    dy, W = rnd(M, N, seed=1), rnd(N, K, seed=2, scale=0.1)
+    ref = dy.double() @ W.double()
+    dx = torch.empty(M, K, device=DEV)
+    ops.linear_bwd_input(dev(dy), dev(W), dx)
+    assert rel_err(dx.cpu(), ref) < GEMM_TOL
+    base = rnd(M, K, seed=5)
+    dx2 = dev(base).clone()
+    ops.linear_bwd_input(dev(dy), dev(W), dx2, accumulate=True)
+    assert rel_err(dx2.cpu(), ref + base.double()) < GEMM_TOL
+    pre = rnd(M, K, seed=6)
+    p64 = pre.double().requires_grad_(True)
+    F.gelu(p64).backward(ref)
+    dx3 = torch.empty(M, K, device=DEV)
+    ops.linear_bwd_input(dev(dy), dev(W), dx3, gelu_pre=dev(pre))
+    assert rel_err(dx3.cpu(), p64.grad) < 5e-6
+
+
+@pytest.mark.parametrize("M,N,K", [(1000, 576, 192), (4160, 192, 768), (70, 10, 24), (33, 4, 16), (650, 48, 96),
+                                    (2080, 768, 192)])
+def test_linear_bwd_weight(ops, M, N, K):
+    dy, x = rnd(M, N, seed=1), rnd(M, K, seed=2)
+    dW_ref, db_ref = dy.double().T @ x.double(), dy.double().sum(0)
+    dW, db = torch.empty(N, K, device=DEV), torch.empty(N, device=DEV)
+    ops.linear_bwd_weight(dev(dy), dev(x), dW, db)
+    assert rel_err(dW.cpu(), dW_ref) < GEMM_TOL
+    assert rel_err(db.cpu(), db_ref) < GEMM_TOL
+    # deterministic: bitwise identical on a second run
+    dW2, db2 = torch.empty(N, K, device=DEV), torch.empty(N, device=DEV)
+    ops.linear_bwd_weight(dev(dy), dev(x), dW2, db2)
+    assert torch.equal(dW, dW2) and torch.equal(db, db2)
+
+
+@pytest.mark.parametrize("B,C,S,p,E", [(6, 3, 32, 4, 192), (4, 1, 28, 2, 16), (3, 3, 8, 4, 24)])
+def test_patch_embed(ops, O, B, C, S, p, E):
+    n = (S // p) ** 2
+    img = rnd(B, C, S, S, seed=1)
+    W, b = rnd(E, C, p, p, seed=2, scale=0.2), rnd(E, seed=3)
+    cls, pos = rnd(1, 1, E, seed=4), O.sincos_pos_embed(E, S // p)
+    P = {"vit.patch_embed.proj.weight": W, "vit.patch_embed.proj.bias": b}
+    ref = torch.cat(((cls + pos[:, :1]).expand(B, -1, -1), O.patch_embed(P, img, p) + pos[:, 1:]), dim=1)
+    tokens = torch.empty(B, n + 1, E, device=DEV)
+    xp = torch.empty(B * n, C * p * p, device=DEV)
+    ops.patch_embed_fwd(dev(img), dev(W.reshape(E, -1).contiguous()), dev(b), dev(pos[0]), dev(cls.reshape(E)), tokens, xp, p)
+    assert torch.allclose(tokens.cpu(), ref, atol=2e-6)
+    # backward
+    dt = rnd(B, n + 1, E, seed=5)
+    Wl = W.clone().requires_grad_(True); bl = b.clone().requires_grad_(True); cl = cls.clone().requires_grad_(True)
+    Pl = {"vit.patch_embed.proj.weight": Wl, "vit.patch_embed.proj.bias": bl}
+    out = torch.cat(((cl + pos[:, :1]).expand(B, -1, -1), O.patch_embed(Pl, img, p) + pos[:, 1:]), dim=1)
+    out.backward(dt)
+    dW, db, dc = torch.empty(E, C * p * p, device=DEV), torch.empty(E, device=DEV), torch.empty(E, device=DEV)
+    ops.patch_embed_bwd(dev(dt), xp, dW, db, dc, B, C, S, p, E)
+    assert rel_err(dW.cpu(), Wl.grad.reshape(E, -1)) < 1e-5
+    assert rel_err(db.cpu(), bl.grad) < 1e-5
+    assert rel_err(dc.cpu(), cl.grad.reshape(E)) < 1e-5
+
+
+@pytest.mark.parametrize("rows,cols", [(130, 192), (70, 96), (37, 16), (20, 4), (9, 768)])
+def test_layernorm(ops, rows, cols):
+    x = rnd(rows, cols, seed=1) * 2 + 0.5
+    g, b = 1 + 0.1 * rnd(cols, seed=2), 0.1 * rnd(cols, seed=3)
+    xl, gl, bl = (t.clone().double().requires_grad_(True) for t in (x, g, b))
+    ref = F.layer_norm(xl, (cols,), gl, bl, 1e-6)
+    y = torch.empty(rows, cols, device=DEV); mean = torch.empty(rows, device=DEV); rstd = torch.empty(rows, device=DEV)
+    ops.layernorm_fwd(dev(x), dev(g), dev(b), y, mean, rstd, 1e-6)
+    assert torch.allclose(y.cpu().double(), ref, atol=3e-6)
+    dy, resid = rnd(rows, cols, seed=4), rnd(rows, cols, seed=5)
+    ref.backward(dy.double())
+    dx = torch.empty(rows, cols, device=DEV); dg = torch.empty(cols, device=DEV); db = torch.empty(cols, device=DEV)
+    ops.layernorm_bwd(dev(dy), dev(x), mean, rstd, dev(g), dev(resid), dx, dg, db)
+    assert rel_err(dx.cpu(), xl.grad + resid.double()) < 5e-6
+    assert rel_err(dg.cpu(), gl.grad) < 5e-6 and rel_err(db.cpu(), bl.grad) < 5e-6
+    dx2 = torch.empty(rows, cols, device=DEV)
+    ops.layernorm_bwd(dev(dy), dev(x), mean, rstd, dev(g), None, dx2, dg, db)
+    assert rel_err(dx2.cpu(), xl.grad) < 5e-6
+
+
+def attn_ref(qkv, B, N, H, hd):
+    q, k, v = qkv.reshape(B, N, 3, H, hd).permute(2, 0, 3, 1, 4)
+    a = ((q @ k.transpose(-2, -1)) * hd ** -0.5).softmax(-1)
+    return (a @ v).transpose(1, 2).reshape(B, N, H * hd)
+
+
+@pytest.mark.parametrize("B,N,H,hd", [(4, 65, 3, 64), (3, 17, 2, 8), (2, 37, 2, 2), (3, 5, 3, 4), (2, 65, 3, 32),
+                                       (2, 197, 2, 8), (1, 257, 3, 64), (2, 16, 1, 16), (2, 33, 2, 3)])
+def test_attention(ops, B, N, H, hd):
+    E = H * hd
+    qkv = rnd(B, N, 3 * E, seed=1)
+    q64 = qkv.double().requires_grad_(True)
+    ref = attn_ref(q64, B, N, H, hd)
+    out = torch.empty(B, N, E, device=DEV); lse = torch.empty(B, H, N, device=DEV)
+    ops.attention_fwd(dev(qkv), out, lse, B, N, H, hd)
+    assert torch.allclose(out.cpu().double(), ref, atol=3e-6), float((out.cpu().double() - ref).abs().max())
+    dout = rnd(B, N, E, seed=2)
+    ref.backward(dout.double())
+    dqkv = torch.full((B, N, 3 * E), float("nan"), device=DEV); delta = torch.empty(B, H, N, device=DEV)
+    ops.attention_bwd(dev(qkv), out, dev(dout), lse, dqkv, delta, B, N, H, hd)
+    assert rel_err(dqkv.cpu(), q64.grad) < 5e-6
+
+
+def test_attention_large_scores(ops):
+    """online-softmax rescale path: a key in the SECOND 64-key chunk dominates."""
+    B, N, H, hd = 1, 130, 1, 16
+    qkv = rnd(B, N, 3 * hd, seed=3)
+    qkv[0, 100, hd:2 * hd] *= 30.0
+    q64 = qkv.double()
+    ref = attn_ref(q64, B, N, H, hd)
+    out = torch.empty(B, N, hd, device=DEV); lse = torch.empty(B, H, N, device=DEV)
+    ops.attention_fwd(dev(qkv), out, lse, B, N, H, hd)
+    assert torch.allclose(out.cpu().double(), ref, atol=1e-5)
+
+
+def bmu_policy_ok(bmu, dist_ref64, eps=2e-6):
+    """BMU exact wherever the fp64 reference's top-2 gap exceeds eps; inside a near-tie either
+    of the tied prototypes is accepted (SURVEY.md hard part 3)."""
+    ref = dist_ref64.argmin(1)
+    srt = dist_ref64.sort(1).values
+    gap = srt[:, 1] - srt[:, 0] if dist_ref64.shape[1] > 1 else torch.ones(dist_ref64.shape[0])
+    chosen = dist_ref64.gather(1, bmu.view(-1, 1)).squeeze(1)
+    exact = (bmu == ref)
+    near = (chosen - srt[:, 0]) <= eps
+    return bool(((exact) | (near & (gap <= eps))).all()), int((~exact).sum())
+
+
+@pytest.mark.parametrize("B,K,L", [(70, 15, 256), (64, 576, 3136), (128, 16, 12288), (33, 100, 48), (5, 7, 20)])
+def test_bmu_cosine(ops, O, B, K, L):
+    x = rnd(B, L, seed=1)
+    W = F.normalize(torch.rand(K, L, generator=torch.Generator().manual_seed(2)), dim=1)
+    dist_ref, bmu_ref = O.som_forward(x, W)
+    d64 = 1 - F.normalize(x.double(), dim=1) @ F.normalize(W.double(), dim=1).T
+    xd, Wd = dev(x), dev(W)
+    inx, inw = torch.empty(B, device=DEV), torch.empty(K, device=DEV)
+    ops.row_inv_norm(xd, inx); ops.row_inv_norm(Wd, inw)
+    assert torch.allclose(inx.cpu(), 1 / x.norm(dim=1), rtol=2e-6)
+    dist, bmu = torch.empty(B, K, device=DEV), torch.empty(B, dtype=torch.int64, device=DEV)
+    ops.bmu_cosine_fwd(xd, Wd, inx, inw, dist, bmu)
+    # distances: 1e-5 abs vs the fp32 oracle (north_star bar 1e-4); 2e-6 vs fp64
+    assert torch.allclose(dist.cpu(), dist_ref, atol=1e-5)
+    assert float((dist.cpu().double() - d64).abs().max()) < 2e-6
+    # bmu is exactly the first argmin of the distances this kernel returned ...
+    assert torch.equal(bmu.cpu(), dist.cpu().argmin(1))
+    # ... and equals the reference BMU outside fp32 near-ties
+    ok, nmis = bmu_policy_ok(bmu.cpu(), d64)
+    assert ok, f"{nmis} BMU mismatches outside near-ties"
+    bmu2 = torch.empty(B, dtype=torch.int64, device=DEV)
+    ops.bmu_cosine_fwd(xd, Wd, inx, inw, None, bmu2)
+    assert torch.equal(bmu, bmu2)
+
+
+def test_bmu_exact_ties_pick_lowest_index(ops):
+    B, K, L = 8, 40, 64
+    x = rnd(B, L, seed=1)
+    W = torch.rand(K, L, generator=torch.Generator().manual_seed(2))
+    W[7] = x[0]; W[3] = x[0]; W[30] = x[0]          # three identical prototypes: exact tie for sample 0
+    xd, Wd = dev(x), dev(W)
+    inx, inw = torch.empty(B, device=DEV), torch.empty(K, device=DEV)
+    ops.row_inv_norm(xd, inx); ops.row_inv_norm(Wd, inw)
+    dist, bmu = torch.empty(B, K, device=DEV), torch.empty(B, dtype=torch.int64, device=DEV)
+    ops.bmu_cosine_fwd(xd, Wd, inx, inw, dist, bmu)
+    assert int(bmu[0]) == 3
+    assert torch.equal(bmu.cpu(), dist.cpu().argmin(1))
+
+
+@pytest.mark.parametrize("B,K,L,map_size,topo", [(70, 15, 256, (3, 5), "square"), (64, 576, 3136, (24, 24), "square"),
+                                                  (33, 12, 48, (4, 3), "hexa")])
+def test_som_neigh_loss_and_bwd(ops, O, B, K, L, map_size, topo):
+    Nrow = L + 8
+    xfull = rnd(B, Nrow, seed=1)
+    x = xfull[:, 8:]
+    W = F.normalize(torch.rand(K, L, generator=torch.Generator().manual_seed(2)), dim=1)
+    grid = O.grid_positions(map_size, topo)
+    T, gam = 1.7, 0.37
+    xl, Wl = x.clone().double().requires_grad_(True), W.clone().double().requires_grad_(True)
+    d_ref = O.som_distances(xl, Wl)
+    bmu_ref = d_ref.argmin(1)
+    h_ref = O.neighbourhood(bmu_ref, grid.double(), T)
+    loss_ref = O.som_loss(h_ref, d_ref)
+    (gam * loss_ref).backward()
+
+    xd = dev(xfull)[:, 8:]; Wd = dev(W)
+    inx, inw = torch.empty(B, device=DEV), torch.empty(K, device=DEV)
+    ops.row_inv_norm(xd, inx); ops.row_inv_norm(Wd, inw)
+    dist, bmu = torch.empty(B, K, device=DEV), torch.empty(B, dtype=torch.int64, device=DEV)
+    ops.bmu_cosine_fwd(xd, Wd, inx, inw, dist, bmu)
+    assert torch.equal(bmu.cpu(), bmu_ref)
+    h = torch.empty(B, K, device=DEV); loss = torch.zeros(1, device=DEV)
+    coef = torch.empty(B, K, device=DEV); rd = torch.empty(B, device=DEV); cd = torch.empty(K, device=DEV)
+    ops.som_neigh_loss(dist, bmu, dev(grid), T, loss, h=h, inv_nx=inx, inv_nw=inw, grad_scale=gam / (B * K), coef=coef,
+                       row_dot=rd, col_dot=cd)
+    assert torch.allclose(h.cpu().double(), h_ref, atol=2e-6)
+    assert abs(float(loss) / (B * K) - float(loss_ref)) < 1e-6
+    gW = torch.empty(K, L, device=DEV)
+    base = rnd(B, Nrow, seed=9)
+    gXfull = dev(base).clone()
+    ops.som_bwd(xd, Wd, coef, rd, cd, gW, gXfull[:, 8:], accumulate_gx=True)
+    # gradients compared relatively (they carry 1/(B K))
+    assert rel_err(gW.cpu(), Wl.grad) < 2e-5
+    assert rel_err(gXfull.cpu()[:, 8:] - base[:, 8:], xl.grad) < 2e-5
+    assert torch.equal(gXfull.cpu()[:, :8], base[:, :8])
+    # forward-only form
+    loss2 = torch.zeros(1, device=DEV)
+    ops.som_neigh_loss(dist, bmu, dev(grid), T, loss2)
+    assert float(loss2) == float(loss)
+
+
+@pytest.mark.parametrize("B,C,S,p", [(6, 3, 32, 4), (4, 1, 28, 2), (3, 3, 8, 4)])
+def test_l1_unpatchify(ops, O, B, C, S, p):
+    n = (S // p) ** 2
+    pred = rnd(B, n + 1, p * p * C, seed=1)
+    img = rnd(B, C, S, S, seed=2)
+    pl = pred.clone().requires_grad_(True)
+    recon_ref = O.unpatchify(pl[:, 1:, :], p)
+    loss_ref = F.l1_loss(recon_ref, img)
+    loss_ref.backward()
+    recon = torch.empty(B, C, S, S, device=DEV); loss = torch.zeros(1, device=DEV); dpred = torch.empty_like(pred, device=DEV)
+    ops.l1_unpatchify(dev(pred), dev(img), loss, recon=recon, dpred=dpred, grad_scale=1.0 / img.numel(), p=p)
+    assert torch.equal(recon.cpu(), recon_ref.detach())
+    assert abs(float(loss) / img.numel() - float(loss_ref)) < 1e-6
+    assert torch.allclose(dpred.cpu(), pl.grad, atol=1e-9)
+
+
+@pytest.mark.parametrize("B,C", [(64, 10), (33, 100), (5, 200), (7, 5)])
+def test_cross_entropy_ls(ops, B, C):
+    z = rnd(B, C, seed=1) * 3
+    y = torch.randint(0, C, (B,), generator=torch.Generator().manual_seed(2))
+    zl = z.clone().double().requires_grad_(True)
+    ref = F.cross_entropy(zl, y, label_smoothing=0.1)
+    ref.backward()
+    loss = torch.zeros(1, device=DEV); dz = torch.empty(B, C, device=DEV)
+    ops.cross_entropy_ls(dev(z), dev(y), 0.1, loss, dlogits=dz, grad_scale=1.0 / B)
+    assert abs(float(loss) / B - float(ref)) < 2e-6
+    assert rel_err(dz.cpu(), zl.grad) < 5e-6
+
+
+def test_adamw_step(ops):
+    n = 256 * 5
+    g0 = torch.Generator().manual_seed(0)
+    p, gr = torch.randn(n, generator=g0), torch.randn(n, generator=g0)
+    wd_chunk = torch.tensor([0.05, 0.0, 0.01, 0.05, 0.0])
+    leaves = [p[256 * i:256 * (i + 1)].clone().requires_grad_(True) for i in range(5)]
+    opt = torch.optim.AdamW([{"params": [l], "weight_decay": float(w)} for l, w in zip(leaves, wd_chunk)], lr=3e-3,
+                            betas=(0.9, 0.999))
+    pd, gd = dev(p).clone(), dev(gr)
+    m, v = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    for step in range(1, 5):
+        for i, l in enumerate(leaves):
+            l.grad = gr[256 * i:256 * (i + 1)].clone() * 0.5       # grad_scale = 0.5
+        opt.step()
+        ops.adamw_step(pd, gd, m, v, dev(wd_chunk), 3e-3, 0.9, 0.999, 1e-8, step, grad_scale=0.5)
+        ref = torch.cat([l.detach() for l in leaves])
+        assert torch.allclose(pd.cpu(), ref, atol=2e-7), step
+
+
+def test_fill_and_reduce(ops):
+    t = torch.empty(1000, device=DEV)
+    ops.fill(t, 2.5)
+    assert bool((t == 2.5).all())
+    slabs = rnd(7, 1003, seed=1)
+    out = torch.empty(1003, device=DEV)
+    ops.reduce_slabs(dev(slabs), out)
+    assert torch.allclose(out.cpu(), slabs.sum(0), atol=1e-5)
+
+
+def test_errors_are_loud(ops):
+    from vit_som_amd._lib import VsomError
+    x = torch.empty(4, 2048, device=DEV)
+    with pytest.raises(VsomError):
+        ops.layernorm_fwd(x, x[0], x[0], torch.empty_like(x), torch.empty(4, device=DEV), torch.empty(4, device=DEV))
+    with pytest.raises(ValueError):
+        ops.linear_fwd(torch.empty(4, 4), torch.empty(4, 4), None, torch.empty(4, 4))   # CPU tensors

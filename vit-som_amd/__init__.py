@@ -1,0 +1,4 @@
+"""vit_som_amd: MI355X-native (gfx950) ViT-SOM training step behind the reference's
+``ViTSOM`` / ``SOMLayer`` module surface (models/vit_som.py, models/som_layer.py)."""
+from . import _lib  # noqa: F401  (fails loudly when libvitsom_hip.so is absent)
+from . import ops  # noqa: F401

@@ -1,0 +1,96 @@
+"""ctypes binding of libvitsom_hip.so (the C-ABI declared in include/vitsom_hip.h).
+
+There is NO fallback: if the shared library is missing the import fails loudly, and every
+wrapper raises ``VsomError`` on a non-zero status.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvitsom_hip.so")
+
+c_fp = C.c_void_p      # float* / int64_t* / void*  (device pointers travel as integers)
+c_stream = C.c_void_p
+
+# name -> (restype, argtypes); mirrors include/vitsom_hip.h one to one (tests/test_abi.py checks)
+SIGNATURES = {
+    "vsom_version": (C.c_int, []),
+    "vsom_last_error_string": (C.c_char_p, []),
+    "vsom_linear_fwd": (C.c_int, [c_fp, C.c_long, c_fp, c_fp, c_fp, C.c_long, C.c_int, C.c_int, C.c_int, c_stream]),
+    "vsom_linear_gelu_fwd": (C.c_int, [c_fp, C.c_long, c_fp, c_fp, c_fp, c_fp, C.c_int, C.c_int, C.c_int, c_stream]),
+    "vsom_linear_residual_fwd": (C.c_int, [c_fp, C.c_long, c_fp, c_fp, c_fp, C.c_long, C.c_int, c_fp, C.c_long,
+                                           C.c_int, C.c_int, C.c_int, c_stream]),
+    "vsom_linear_bwd_input": (C.c_int, [c_fp, C.c_long, c_fp, c_fp, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int,
+                                        c_fp, c_stream]),
+    "vsom_linear_bwd_weight_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "vsom_linear_bwd_weight": (C.c_int, [c_fp, C.c_long, c_fp, C.c_long, c_fp, c_fp, C.c_int, C.c_int, C.c_int,
+                                         c_fp, C.c_size_t, c_stream]),
+    "vsom_patch_embed_fwd": (C.c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, C.c_int, C.c_int, C.c_int, C.c_int,
+                                       C.c_int, c_stream]),
+    "vsom_patch_embed_bwd_workspace_bytes": (C.c_size_t, [C.c_int] * 5),
+    "vsom_patch_embed_bwd": (C.c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                       c_fp, C.c_size_t, c_stream]),
+    "vsom_layernorm_fwd": (C.c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, C.c_int, C.c_int, C.c_float, c_stream]),
+    "vsom_layernorm_bwd_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "vsom_layernorm_bwd": (C.c_int, [c_fp] * 9 + [C.c_int, C.c_int, c_fp, C.c_size_t, c_stream]),
+    "vsom_attention_fwd": (C.c_int, [c_fp, c_fp, c_fp, C.c_int, C.c_int, C.c_int, C.c_int, c_stream]),
+    "vsom_attention_bwd": (C.c_int, [c_fp] * 6 + [C.c_int] * 4 + [c_stream]),
+    "vsom_row_inv_norm": (C.c_int, [c_fp, C.c_long, C.c_int, C.c_int, C.c_float, c_fp, c_stream]),
+    "vsom_bmu_cosine_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "vsom_bmu_cosine_fwd": (C.c_int, [c_fp, C.c_long, c_fp, c_fp, c_fp, c_fp, c_fp, C.c_int, C.c_int, C.c_int, c_fp,
+                                      C.c_size_t, c_stream]),
+    "vsom_som_neigh_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "vsom_som_neigh_loss": (C.c_int, [c_fp, c_fp, c_fp, C.c_float, c_fp, c_fp, C.c_float, c_fp, c_fp, c_fp, c_fp,
+                                      c_fp, C.c_int, C.c_int, c_fp, C.c_size_t, c_stream]),
+    "vsom_som_bwd": (C.c_int, [c_fp, C.c_long, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, C.c_long, C.c_int, C.c_int,
+                               C.c_int, C.c_int, c_stream]),
+    "vsom_l1_unpatchify_workspace_bytes": (C.c_size_t, [C.c_int] * 4),
+    "vsom_l1_unpatchify": (C.c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int,
+                                     c_fp, C.c_size_t, c_stream]),
+    "vsom_cross_entropy_ls_workspace_bytes": (C.c_size_t, [C.c_int]),
+    "vsom_cross_entropy_ls": (C.c_int, [c_fp, c_fp, C.c_float, c_fp, c_fp, C.c_float, C.c_int, C.c_int, c_fp,
+                                        C.c_size_t, c_stream]),
+    "vsom_adamw_step": (C.c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, C.c_long, C.c_float, C.c_float, C.c_float, C.c_float,
+                                  C.c_int, C.c_float, C.c_int, c_stream]),
+    "vsom_fill": (C.c_int, [c_fp, C.c_long, C.c_float, c_stream]),
+    "vsom_reduce_slabs": (C.c_int, [c_fp, C.c_long, C.c_int, c_fp, C.c_long, c_stream]),
+}
+
+
+class VsomError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  vit_som_amd has no CPU/eager fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the .so does not export it
+        fn.restype, fn.argtypes = res, args
+    return lib
+
+
+lib = _load()
+
+
+def last_error() -> str:
+    return lib.vsom_last_error_string().decode()
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        raise VsomError(f"{what} failed with status {rc}: {last_error()}")
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,67 @@
+// Shared host/device helpers for libvitsom_hip.so (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/vitsom_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace vsom {
+
+// thread-local last-error text (vsom_last_error_string)
+void set_error(const char* fmt, ...);
+
+inline int hip_status(hipError_t e, const char* what) {
+    if (e == hipSuccess) return VSOM_OK;
+    set_error("%s: %s", what, hipGetErrorString(e));
+    return (int)e;
+}
+
+#define VSOM_REQUIRE(cond, code, ...)      \
+    do {                                   \
+        if (!(cond)) {                     \
+            ::vsom::set_error(__VA_ARGS__); \
+            return (code);                 \
+        }                                  \
+    } while (0)
+
+#define VSOM_LAUNCH_CHECK(name) return ::vsom::hip_status(hipGetLastError(), name)
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// ---------------------------------------------------------------- device helpers
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+__device__ __forceinline__ float gelu_erf(float x) {           // nn.GELU() default (exact erf)
+    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+
+// XCD-aware bijective block remap (MI355X: 8 XCDs, blocks dealt round-robin).  Blocks that share
+// an XCD (equal b % 8) get a contiguous range of logical ids, so tiles that share an operand
+// panel hit the same per-XCD L2.  Speed only, never correctness.
+__device__ __forceinline__ int xcd_remap(int b, int nblk) {
+    const int q = nblk >> 3, r = nblk & 7, x = b & 7, i = b >> 3;
+    const int base = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+    return base + i;
+}
+
+}  // namespace vsom

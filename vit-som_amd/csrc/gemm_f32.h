@@ -1,0 +1,289 @@
+// Exact-fp32 MFMA GEMM engine for gfx950 (v_mfma_f32_32x32x2_f32: bitwise an fmaf chain).
+//
+//   C[M,N] = epilogue( sum_k opA(m,k) * opB(k,n) )
+//
+// Operand storage modes (the reduction index is "k"):
+//   A_KC  : A element (m,k) at A[m*lda + k]   (k contiguous)      else A[k*lda + m] (k strided)
+//   B_KC  : B element (k,n) at B[n*ldb + k]   (k contiguous)      else B[k*ldb + n] (k strided)
+//   forward  Linear  Y = X W^T      : A_KC,  B_KC   ("NT")
+//   input    grad    dX = dY W      : A_KC, !B_KC   ("NN")
+//   weight   grad    dW = dY^T X    : !A_KC, !B_KC  ("TN", split over the reduction -> slabs)
+//
+// Tiling: 256 threads = 4 waves; block tile BM x BN (128x128 or 128x64), BK = 32; each wave owns
+// WM x WN tiles of 32x32 (16 accumulator VGPRs each).  Operand tiles are staged global ->
+// registers -> LDS (one LDS buffer, next tile's global loads in flight during the MFMAs); with
+// f32 MFMA at 64 cycles per instruction the 2-4 co-resident workgroups per CU cover the staging.
+// LDS images: k-contiguous tiles are [rows][36] (row stride 144 B: conflict-free ds_read_b128 of
+// 4 consecutive k per lane), k-strided tiles are [32][cols+4] (ds_read_b32 across 32 consecutive
+// columns).  Lane l = (r = l & 31, h = l >> 5) feeds MFMA step s of an 8-deep group with
+// k = kb + 4h + s for BOTH operands, so any consistent assignment is exact.
+#pragma once
+#include "common.h"
+
+namespace vsom {
+
+enum Epi : int {
+    EPI_NONE = 0,       // v = alpha*acc (+ C if accumulate)
+    EPI_BIAS = 1,       // v = acc + bias[n]
+    EPI_BIAS_GELU = 2,  // pre = acc + bias[n]; C = pre; C2 = gelu(pre)
+    EPI_BIAS_RES = 3,   // v = acc + bias[n] + R[(m % r_mod + r_off)*ldr + n]; output row map
+    EPI_ROWAXPY = 4,    // v = acc + rowscale[m]*R[m*ldr + n] (+ C if accumulate)
+    EPI_GELU_BWD = 5,   // v = acc * gelu'(R[m*ldr + n]) (+ C if accumulate)
+    EPI_SLAB = 6,       // split-k partial: slab[z][m*N + n] = acc; optional column sums of A
+};
+
+struct GemmP {
+    const float* A; const float* B; float* C;
+    long lda, ldb, ldc;
+    int M, N, K;
+    int ktiles_per_split;        // k-tiles (of 32) handled by one blockIdx.z
+    // reduction-row map for a k-strided A (rows of A are reduction indices):
+    //   row(k) = (k / a_seg)*a_stride + a_off + k % a_seg ; a_seg == 0 -> identity
+    int a_seg, a_stride, a_off;
+    // output-row map, same form (c_seg == 0 -> identity)
+    int c_seg, c_stride, c_off;
+    const float* bias;
+    const float* R; long ldr; int r_mod, r_off;
+    float* C2; long ldc2;
+    const float* rowscale;
+    float alpha; int accumulate;
+    float* slab; long slab_stride;   // EPI_SLAB
+    float* slab_bias; long slab_bias_stride;   // per-split column sums of A (bias gradient), or null
+    int a_vec, b_vec;            // 16-byte vector loads legal for A / B
+};
+
+template <int R_>
+struct StageRegs { f32x4 v[R_ / 32]; };
+
+// ---- global -> register staging ------------------------------------------------------------
+// k-contiguous tile: ROWS x 32, thread t loads float4 at (row = p*32 + t/8, k = (t%8)*4)
+template <int ROWS>
+__device__ __forceinline__ void load_kc(StageRegs<ROWS>& s, const float* __restrict__ base, long ld,
+                                        int row0, int nrows, int k0, int K, int vec, int t) {
+#pragma unroll
+    for (int p = 0; p < ROWS / 32; ++p) {
+        const int row = row0 + p * 32 + (t >> 3);
+        const int k = k0 + ((t & 7) << 2);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (row < nrows && k < K) {
+            const float* src = base + (long)row * ld + k;
+            if (vec && k + 3 < K) {
+                v = *reinterpret_cast<const f32x4*>(src);
+            } else {
+                v[0] = src[0];
+                if (k + 1 < K) v[1] = src[1];
+                if (k + 2 < K) v[2] = src[2];
+                if (k + 3 < K) v[3] = src[3];
+            }
+        }
+        s.v[p] = v;
+    }
+}
+template <int ROWS>
+__device__ __forceinline__ void store_kc(const StageRegs<ROWS>& s, float* lds, int t) {
+#pragma unroll
+    for (int p = 0; p < ROWS / 32; ++p)
+        *reinterpret_cast<f32x4*>(lds + (p * 32 + (t >> 3)) * 36 + ((t & 7) << 2)) = s.v[p];
+}
+// k-strided tile: 32 x COLS, thread t loads float4 at (k = p*KPP + t/(COLS/4), col = (t%(COLS/4))*4)
+template <int COLS>
+__device__ __forceinline__ void load_ks(StageRegs<COLS>& s, const float* __restrict__ base, long ld,
+                                        int col0, int ncols, int k0, int K, int vec, int t, int seg,
+                                        int stride, int off) {
+    constexpr int TPR = COLS / 4;        // threads per k-row
+    constexpr int KPP = 256 / TPR;       // k-rows per pass
+#pragma unroll
+    for (int p = 0; p < COLS / 32; ++p) {
+        const int k = k0 + p * KPP + t / TPR;
+        const int col = col0 + ((t % TPR) << 2);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (k < K && col < ncols) {
+            const long row = seg ? (long)(k / seg) * stride + off + (k % seg) : (long)k;
+            const float* src = base + row * ld + col;
+            if (vec && col + 3 < ncols) {
+                v = *reinterpret_cast<const f32x4*>(src);
+            } else {
+                v[0] = src[0];
+                if (col + 1 < ncols) v[1] = src[1];
+                if (col + 2 < ncols) v[2] = src[2];
+                if (col + 3 < ncols) v[3] = src[3];
+            }
+        }
+        s.v[p] = v;
+    }
+}
+template <int COLS>
+__device__ __forceinline__ void store_ks(const StageRegs<COLS>& s, float* lds, int t) {
+    constexpr int TPR = COLS / 4;
+    constexpr int KPP = 256 / TPR;
+#pragma unroll
+    for (int p = 0; p < COLS / 32; ++p)
+        *reinterpret_cast<f32x4*>(lds + (p * KPP + t / TPR) * (COLS + 4) + ((t % TPR) << 2)) = s.v[p];
+}
+
+template <bool A_KC, bool B_KC, int WM, int WN, int WAVES_M, int WAVES_N, int EPI>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmP g) {
+    constexpr int BM = WAVES_M * WM * 32;
+    constexpr int BN = WAVES_N * WN * 32;
+    constexpr int A_LDS = A_KC ? BM * 36 : 32 * (BM + 4);
+    constexpr int B_LDS = B_KC ? BN * 36 : 32 * (BN + 4);
+    __shared__ __attribute__((aligned(16))) float lds[A_LDS + B_LDS];
+    float* As = lds;
+    float* Bs = lds + A_LDS;
+
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int wm0 = (wave / WAVES_N) * (WM * 32);
+    const int wn0 = (wave % WAVES_N) * (WN * 32);
+
+    const int tiles_n = (g.N + BN - 1) / BN;
+    const int nblk = gridDim.x;
+    const int bid = xcd_remap(blockIdx.x, nblk);
+    const int bm0 = (bid / tiles_n) * BM;
+    const int bn0 = (bid % tiles_n) * BN;
+    const int z = blockIdx.z;
+
+    const int ktiles = (g.K + 31) >> 5;
+    const int kt_begin = z * g.ktiles_per_split;
+    int kt_end = kt_begin + g.ktiles_per_split;
+    if (kt_end > ktiles) kt_end = ktiles;
+
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+
+    float colsum = 0.f;                       // EPI_SLAB bias partial (thread t < BM owns A column t)
+    const bool want_colsum = (EPI == EPI_SLAB) && !A_KC && g.slab_bias != nullptr && (bid % tiles_n) == 0;
+
+    StageRegs<BM> sa;
+    StageRegs<BN> sb;
+    auto gload = [&](int kt) {
+        const int k0 = kt << 5;
+        if constexpr (A_KC) load_kc<BM>(sa, g.A, g.lda, bm0, g.M, k0, g.K, g.a_vec, t);
+        else load_ks<BM>(sa, g.A, g.lda, bm0, g.M, k0, g.K, g.a_vec, t, g.a_seg, g.a_stride, g.a_off);
+        if constexpr (B_KC) load_kc<BN>(sb, g.B, g.ldb, bn0, g.N, k0, g.K, g.b_vec, t);
+        else load_ks<BN>(sb, g.B, g.ldb, bn0, g.N, k0, g.K, g.b_vec, t, 0, 0, 0);
+    };
+    auto lstore = [&]() {
+        if constexpr (A_KC) store_kc<BM>(sa, As, t); else store_ks<BM>(sa, As, t);
+        if constexpr (B_KC) store_kc<BN>(sb, Bs, t); else store_ks<BN>(sb, Bs, t);
+    };
+
+    if (kt_begin < kt_end) {
+        gload(kt_begin);
+        lstore();
+    }
+    __syncthreads();
+
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        const bool more = (kt + 1 < kt_end);
+        if (more) gload(kt + 1);               // global loads stay in flight under the MFMAs
+
+        if (want_colsum && t < BM) {
+            float s = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < 32; ++kk) s += As[kk * (BM + 4) + t];
+            colsum += s;
+        }
+
+#pragma unroll
+        for (int kb = 0; kb < 32; kb += 8) {
+            f32x4 a[WM], b[WN];
+#pragma unroll
+            for (int i = 0; i < WM; ++i) {
+                if constexpr (A_KC) {
+                    a[i] = *reinterpret_cast<const f32x4*>(As + (wm0 + i * 32 + r) * 36 + kb + 4 * h);
+                } else {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) a[i][s] = As[(kb + 4 * h + s) * (BM + 4) + wm0 + i * 32 + r];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < WN; ++j) {
+                if constexpr (B_KC) {
+                    b[j] = *reinterpret_cast<const f32x4*>(Bs + (wn0 + j * 32 + r) * 36 + kb + 4 * h);
+                } else {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) b[j][s] = Bs[(kb + 4 * h + s) * (BN + 4) + wn0 + j * 32 + r];
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int i = 0; i < WM; ++i)
+#pragma unroll
+                    for (int j = 0; j < WN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+        if (more) {
+            lstore();
+            __syncthreads();
+        }
+    }
+
+    // ---------------------------------------------------------------- epilogue
+    if constexpr (EPI == EPI_SLAB) {
+        if (want_colsum && t < BM && bm0 + t < g.M) g.slab_bias[(long)z * g.slab_bias_stride + bm0 + t] = colsum;
+    }
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+            const int n = bn0 + wn0 + j * 32 + r;
+            if (n >= g.N) continue;
+            float bn = 0.f;
+            if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RES)
+                bn = g.bias ? g.bias[n] : 0.f;
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int m = bm0 + wm0 + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
+                if (m >= g.M) continue;
+                const float a = acc[i][j][v];
+                if constexpr (EPI == EPI_SLAB) {
+                    g.slab[(long)z * g.slab_stride + (long)m * g.N + n] = a;
+                } else {
+                    const long orow = g.c_seg ? (long)(m / g.c_seg) * g.c_stride + g.c_off + (m % g.c_seg) : (long)m;
+                    float* dst = g.C + orow * g.ldc + n;
+                    if constexpr (EPI == EPI_NONE) {
+                        float val = g.alpha * a;
+                        if (g.accumulate) val += *dst;
+                        *dst = val;
+                    } else if constexpr (EPI == EPI_BIAS) {
+                        *dst = a + bn;
+                    } else if constexpr (EPI == EPI_BIAS_GELU) {
+                        const float pre = a + bn;
+                        *dst = pre;
+                        g.C2[(long)m * g.ldc2 + n] = gelu_erf(pre);
+                    } else if constexpr (EPI == EPI_BIAS_RES) {
+                        const long rr = (long)(m % g.r_mod) + g.r_off;
+                        *dst = a + bn + g.R[rr * g.ldr + n];
+                    } else if constexpr (EPI == EPI_ROWAXPY) {
+                        float val = a + g.rowscale[m] * g.R[(long)m * g.ldr + n];
+                        if (g.accumulate) val += *dst;
+                        *dst = val;
+                    } else if constexpr (EPI == EPI_GELU_BWD) {
+                        float val = a * gelu_erf_grad(g.R[(long)m * g.ldr + n]);
+                        if (g.accumulate) val += *dst;
+                        *dst = val;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// host-side launcher (gemm_f32.hip)
+int launch_gemm(bool a_kc, bool b_kc, int epi, GemmP g, int splits, hipStream_t stream);
+int linear_bwd_weight_impl(const float* dY, long lddy, const float* X, long ldx, float* dW, float* db, int M, int N,
+                           int K, int a_seg, int a_stride, int a_off, void* ws, size_t ws_bytes,
+                           hipStream_t stream);
+int reduce_slabs_internal(const float* slabs, long stride, int nslabs, float* out, long n, hipStream_t stream);
+int sum_partials(const float* part, int n, float* out, hipStream_t stream);
+
+}  // namespace vsom

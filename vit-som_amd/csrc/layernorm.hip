@@ -1,0 +1,162 @@
+// LayerNorm forward / backward: one wave per token row, row held in registers, 16 B-free
+// scalar-coalesced accesses (rows are 4..1024 floats; E = 192 -> 3 values per lane).
+#include "gemm_f32.h"
+
+namespace vsom {
+
+template <int MAXV>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ X,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta,
+                                                            float* __restrict__ Y, float* __restrict__ mean,
+                                                            float* __restrict__ rstd, int rows, int cols,
+                                                            float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* x = X + (long)row * cols;
+    float v[MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAXV; ++j) {
+        const int c = lane + 64 * j;
+        v[j] = (c < cols) ? x[c] : 0.f;
+        s += v[j];
+    }
+    const float mu = wave_sum(s) / (float)cols;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAXV; ++j) {
+        const int c = lane + 64 * j;
+        const float d = (c < cols) ? v[j] - mu : 0.f;
+        q = fmaf(d, d, q);
+    }
+    const float rs = rsqrtf(wave_sum(q) / (float)cols + eps);
+    float* y = Y + (long)row * cols;
+#pragma unroll
+    for (int j = 0; j < MAXV; ++j) {
+        const int c = lane + 64 * j;
+        if (c < cols) y[c] = (v[j] - mu) * rs * gamma[c] + beta[c];
+    }
+    if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+}
+
+// dX = resid + rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dY * gamma
+// per-workgroup partial sums of dgamma = sum dY*xhat and dbeta = sum dY go to ws[blk][2][cols]
+template <int MAXV>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dY,
+                                                            const float* __restrict__ X,
+                                                            const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ resid,
+                                                            float* __restrict__ dX, float* __restrict__ part,
+                                                            int rows, int cols) {
+    extern __shared__ __attribute__((aligned(16))) float sh[];   // [4 waves][2][cols]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float gam[MAXV], dg[MAXV], db[MAXV];
+#pragma unroll
+    for (int j = 0; j < MAXV; ++j) {
+        const int c = lane + 64 * j;
+        gam[j] = (c < cols) ? gamma[c] : 0.f;
+        dg[j] = 0.f; db[j] = 0.f;
+    }
+    const float inv_n = 1.0f / (float)cols;
+    for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+        const float mu = mean[row], rs = rstd[row];
+        const float* x = X + (long)row * cols;
+        const float* dy = dY + (long)row * cols;
+        float xh[MAXV], g[MAXV];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < MAXV; ++j) {
+            const int c = lane + 64 * j;
+            const bool ok = c < cols;
+            const float d = ok ? dy[c] : 0.f;
+            xh[j] = ok ? (x[c] - mu) * rs : 0.f;
+            g[j] = d * gam[j];
+            s1 += g[j];
+            s2 = fmaf(g[j], xh[j], s2);
+            dg[j] = fmaf(d, xh[j], dg[j]);
+            db[j] += d;
+        }
+        s1 = wave_sum(s1) * inv_n;
+        s2 = wave_sum(s2) * inv_n;
+        float* dx = dX + (long)row * cols;
+        const float* rr = resid ? resid + (long)row * cols : nullptr;
+#pragma unroll
+        for (int j = 0; j < MAXV; ++j) {
+            const int c = lane + 64 * j;
+            if (c < cols) {
+                float val = rs * (g[j] - s1 - xh[j] * s2);
+                if (rr) val += rr[c];
+                dx[c] = val;
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < MAXV; ++j) {
+        const int c = lane + 64 * j;
+        if (c < cols) { sh[(wave * 2 + 0) * cols + c] = dg[j]; sh[(wave * 2 + 1) * cols + c] = db[j]; }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < 2 * cols; c += 256) {
+        const float s = (sh[c] + sh[2 * cols + c]) + (sh[4 * cols + c] + sh[6 * cols + c]);
+        part[(long)blockIdx.x * 2 * cols + c] = s;
+    }
+}
+
+static int ln_bwd_blocks(int rows) {
+    int b = cdiv(rows, 64);          // >= 16 rows per wave
+    if (b > 1024) b = 1024;
+    if (b < 1) b = 1;
+    return b;
+}
+
+}  // namespace vsom
+
+using namespace vsom;
+
+extern "C" {
+
+int vsom_layernorm_fwd(const float* X, const float* gamma, const float* beta, float* Y, float* mean, float* rstd,
+                       int rows, int cols, float eps, vsom_stream_t stream) {
+    VSOM_REQUIRE(X && gamma && beta && Y && mean && rstd, VSOM_EINVAL, "layernorm_fwd: null pointer");
+    VSOM_REQUIRE(rows > 0 && cols > 0, VSOM_EINVAL, "layernorm_fwd: bad shape");
+    VSOM_REQUIRE(cols <= 1024, VSOM_EUNSUPPORTED, "layernorm_fwd: cols=%d > 1024", cols);
+    dim3 grid(cdiv(rows, 4)), block(256);
+    if (cols <= 256)
+        hipLaunchKernelGGL(layernorm_fwd_kernel<4>, grid, block, 0, stream, X, gamma, beta, Y, mean, rstd, rows, cols, eps);
+    else
+        hipLaunchKernelGGL(layernorm_fwd_kernel<16>, grid, block, 0, stream, X, gamma, beta, Y, mean, rstd, rows, cols, eps);
+    VSOM_LAUNCH_CHECK("layernorm_fwd_kernel");
+}
+
+size_t vsom_layernorm_bwd_workspace_bytes(int rows, int cols) {
+    if (rows <= 0 || cols <= 0) return 0;
+    return (size_t)ln_bwd_blocks(rows) * 2 * (size_t)cols * sizeof(float);
+}
+
+int vsom_layernorm_bwd(const float* dY, const float* X, const float* mean, const float* rstd, const float* gamma,
+                       const float* resid, float* dX, float* dgamma, float* dbeta, int rows, int cols, void* ws,
+                       size_t ws_bytes, vsom_stream_t stream) {
+    VSOM_REQUIRE(dY && X && mean && rstd && gamma && dX && dgamma && dbeta, VSOM_EINVAL, "layernorm_bwd: null pointer");
+    VSOM_REQUIRE(rows > 0 && cols > 0, VSOM_EINVAL, "layernorm_bwd: bad shape");
+    VSOM_REQUIRE(cols <= 1024, VSOM_EUNSUPPORTED, "layernorm_bwd: cols=%d > 1024", cols);
+    VSOM_REQUIRE(ws && ws_bytes >= vsom_layernorm_bwd_workspace_bytes(rows, cols), VSOM_EWORKSPACE, "layernorm_bwd: workspace too small");
+    VSOM_REQUIRE(aligned16(ws), VSOM_EALIGN, "layernorm_bwd: workspace must be 16-byte aligned");
+    const int nblk = ln_bwd_blocks(rows);
+    float* part = static_cast<float*>(ws);
+    const size_t shmem = (size_t)8 * cols * sizeof(float);
+    if (cols <= 256)
+        hipLaunchKernelGGL(layernorm_bwd_kernel<4>, dim3(nblk), dim3(256), shmem, stream, dY, X, mean, rstd, gamma, resid, dX, part, rows, cols);
+    else
+        hipLaunchKernelGGL(layernorm_bwd_kernel<16>, dim3(nblk), dim3(256), shmem, stream, dY, X, mean, rstd, gamma, resid, dX, part, rows, cols);
+    int rc = hip_status(hipGetLastError(), "layernorm_bwd_kernel");
+    if (rc) return rc;
+    rc = reduce_slabs_internal(part, 2L * cols, nblk, dgamma, cols, stream);
+    if (rc) return rc;
+    return reduce_slabs_internal(part + cols, 2L * cols, nblk, dbeta, cols, stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,267 @@
+// Patch embedding, losses, fused AdamW, small utilities.
+#include "gemm_f32.h"
+
+namespace vsom {
+
+// ------------------------------------------------------------------ patch gather
+// xp[(b*n + pi), c*p*p + py*p + px] = img[b, c, (pi / g)*p + py, (pi % g)*p + px]
+// (column order = flattened Conv2d weight [E, C, p, p])
+__global__ __launch_bounds__(256) void patch_gather_kernel(const float* __restrict__ img,
+                                                           float* __restrict__ xp, long total, int C, int S,
+                                                           int p, int g) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    // idx enumerates image pixels (coalesced reads); writes are p-float runs
+    const int x = idx % S;
+    const int y = (idx / S) % S;
+    const int c = (idx / ((long)S * S)) % C;
+    const long b = idx / ((long)S * S * C);
+    const int pi = (y / p) * g + (x / p);
+    const int col = c * p * p + (y % p) * p + (x % p);
+    xp[(b * g * g + pi) * (long)(C * p * p) + col] = img[idx];
+}
+
+// tokens[b, 0, :] = cls_token + pos[0]
+__global__ __launch_bounds__(256) void cls_rows_kernel(const float* __restrict__ cls_token,
+                                                       const float* __restrict__ pos, float* __restrict__ tokens,
+                                                       int B, int Ntok, int E) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)B * E) return;
+    const int e = idx % E;
+    const long b = idx / E;
+    tokens[b * Ntok * E + e] = cls_token[e] + pos[e];
+}
+
+// dcls[e] = sum_b dtokens[b, 0, e]   (fixed order)
+__global__ __launch_bounds__(256) void cls_grad_kernel(const float* __restrict__ dtokens, float* __restrict__ dcls,
+                                                       int B, int Ntok, int E) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= E) return;
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += dtokens[(long)b * Ntok * E + e];
+    dcls[e] = s;
+}
+
+// ------------------------------------------------------------------ L1 + unpatchify
+// pred[b, 1+pi, (py*p + px)*C + c]  <->  pixel (b, c, (pi/g)*p + py, (pi%g)*p + px)
+__global__ __launch_bounds__(256) void l1_unpatchify_kernel(const float* __restrict__ pred,
+                                                            const float* __restrict__ img,
+                                                            float* __restrict__ recon, float* __restrict__ part,
+                                                            float* __restrict__ dpred, float gscale, long total,
+                                                            int C, int S, int p, int g) {
+    const int pd = p * p * C, Ntok = g * g + 1;
+    float acc = 0.f;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        // idx enumerates pred elements [B, Ntok, pd]
+        const int j = idx % pd;
+        const int tok = (idx / pd) % Ntok;
+        const long b = idx / ((long)pd * Ntok);
+        if (tok == 0) {
+            if (dpred) dpred[idx] = 0.f;
+            continue;
+        }
+        const int pi = tok - 1;
+        const int c = j % C, px = (j / C) % p, py = j / (C * p);
+        const long pix = ((b * C + c) * S + (pi / g) * p + py) * S + (pi % g) * p + px;
+        const float v = pred[idx];
+        const float d = v - img[pix];
+        if (recon) recon[pix] = v;
+        acc += fabsf(d);
+        if (dpred) dpred[idx] = (d > 0.f) ? gscale : ((d < 0.f) ? -gscale : 0.f);
+    }
+    acc = wave_sum(acc);
+    __shared__ float sh[4];
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+static int l1_blocks(long total) {
+    long b = (total + 1023) / 1024;
+    if (b > 2048) b = 2048;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+// ------------------------------------------------------------------ cross entropy with label smoothing
+// wave per sample row
+__global__ __launch_bounds__(256) void ce_ls_kernel(const float* __restrict__ logits, const int64_t* __restrict__ y,
+                                                    float smoothing, float* __restrict__ part,
+                                                    float* __restrict__ dlogits, float gscale, int B, int C) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= B) return;
+    const float* z = logits + (long)row * C;
+    float mx = -INFINITY;
+    for (int c = lane; c < C; c += 64) mx = fmaxf(mx, z[c]);
+    mx = wave_max(mx);
+    float se = 0.f, sz = 0.f;
+    for (int c = lane; c < C; c += 64) { se += expf(z[c] - mx); sz += z[c]; }
+    se = wave_sum(se);
+    sz = wave_sum(sz);
+    const float lse = mx + logf(se);
+    const int64_t t = y[row];
+    // loss = (1-s) * (lse - z[t]) + s * (lse - mean(z))
+    if (lane == 0) part[row] = (1.f - smoothing) * (lse - z[t]) + smoothing * (lse - sz / (float)C);
+    if (dlogits) {
+        float* dz = dlogits + (long)row * C;
+        const float u = smoothing / (float)C;
+        for (int c = lane; c < C; c += 64) {
+            const float sm = expf(z[c] - lse);
+            dz[c] = gscale * (sm - u - ((c == t) ? (1.f - smoothing) : 0.f));
+        }
+    }
+}
+
+// ------------------------------------------------------------------ AdamW over a flat arena
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                    float* __restrict__ m, float* __restrict__ v,
+                                                    const float* __restrict__ wd_chunk, long n4, float lr,
+                                                    float b1, float b2, float eps, float step_size,
+                                                    float inv_bc2_sqrt, float gscale, int adamw) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const float wd = wd_chunk[i >> 6];              // 64 float4 = 256 elements per chunk
+        f32x4 pp = reinterpret_cast<f32x4*>(p)[i];
+        const f32x4 gg = reinterpret_cast<const f32x4*>(g)[i];
+        f32x4 mm = reinterpret_cast<f32x4*>(m)[i];
+        f32x4 vv = reinterpret_cast<f32x4*>(v)[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float gr = gg[e] * gscale;
+            float pe = pp[e];
+            if (adamw) pe *= (1.f - lr * wd); else gr = fmaf(wd, pe, gr);
+            const float me = mm[e] + (gr - mm[e]) * (1.f - b1);          // lerp_, torch/optim/adam.py
+            const float ve = fmaf(vv[e], b2, (1.f - b2) * gr * gr);
+            const float denom = sqrtf(ve) * inv_bc2_sqrt + eps;
+            pp[e] = pe - step_size * (me / denom);
+            mm[e] = me; vv[e] = ve;
+        }
+        reinterpret_cast<f32x4*>(p)[i] = pp;
+        reinterpret_cast<f32x4*>(m)[i] = mm;
+        reinterpret_cast<f32x4*>(v)[i] = vv;
+    }
+}
+
+__global__ __launch_bounds__(256) void fill_kernel(float* __restrict__ p, long n, float value) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) p[i] = value;
+}
+
+static int grid_for(long n, int per_block, int cap) {
+    long b = (n + per_block - 1) / per_block;
+    if (b > cap) b = cap;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+}  // namespace vsom
+
+using namespace vsom;
+
+extern "C" {
+
+int vsom_fill(float* p, long n, float value, vsom_stream_t stream) {
+    VSOM_REQUIRE(p && n >= 0, VSOM_EINVAL, "fill: bad arguments");
+    if (n == 0) return VSOM_OK;
+    hipLaunchKernelGGL(fill_kernel, dim3(grid_for(n, 1024, 4096)), dim3(256), 0, stream, p, n, value);
+    VSOM_LAUNCH_CHECK("fill_kernel");
+}
+
+int vsom_patch_embed_fwd(const float* img, const float* Wpe, const float* bpe, const float* pos,
+                         const float* cls_token, float* tokens, float* xp_ws, int B, int C, int S, int p, int E,
+                         vsom_stream_t stream) {
+    VSOM_REQUIRE(img && Wpe && bpe && pos && cls_token && tokens && xp_ws, VSOM_EINVAL, "patch_embed_fwd: null pointer");
+    VSOM_REQUIRE(B > 0 && C > 0 && S > 0 && p > 0 && E > 0 && S % p == 0, VSOM_EINVAL, "patch_embed_fwd: bad shape");
+    const int g = S / p, n = g * g, Ntok = n + 1, pd = C * p * p;
+    const long total = (long)B * C * S * S;
+    hipLaunchKernelGGL(patch_gather_kernel, dim3(cdiv(total, 256)), dim3(256), 0, stream, img, xp_ws, total, C, S, p, g);
+    int rc = hip_status(hipGetLastError(), "patch_gather_kernel");
+    if (rc) return rc;
+    // tokens[b, 1+pi, :] = xp[b*n+pi, :] Wpe^T + bpe + pos[1+pi, :]
+    GemmP q = {};
+    q.A = xp_ws; q.lda = pd; q.B = Wpe; q.ldb = pd; q.C = tokens; q.ldc = E;
+    q.M = B * n; q.N = E; q.K = pd; q.bias = bpe;
+    q.R = pos; q.ldr = E; q.r_mod = n; q.r_off = 1;
+    q.c_seg = n; q.c_stride = Ntok; q.c_off = 1;
+    rc = launch_gemm(true, true, EPI_BIAS_RES, q, 1, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(cls_rows_kernel, dim3(cdiv((long)B * E, 256)), dim3(256), 0, stream, cls_token, pos, tokens, B, Ntok, E);
+    VSOM_LAUNCH_CHECK("cls_rows_kernel");
+}
+
+size_t vsom_patch_embed_bwd_workspace_bytes(int B, int C, int S, int p, int E) {
+    if (B <= 0 || C <= 0 || S <= 0 || p <= 0 || E <= 0) return 0;
+    const int n = (S / p) * (S / p);
+    return vsom_linear_bwd_weight_workspace_bytes(B * n, E, C * p * p);
+}
+
+int vsom_patch_embed_bwd(const float* dtokens, const float* xp_ws, float* dWpe, float* dbpe, float* dcls_token,
+                         int B, int C, int S, int p, int E, void* ws, size_t ws_bytes, vsom_stream_t stream) {
+    VSOM_REQUIRE(dtokens && xp_ws && dWpe && dbpe && dcls_token, VSOM_EINVAL, "patch_embed_bwd: null pointer");
+    VSOM_REQUIRE(B > 0 && C > 0 && S > 0 && p > 0 && E > 0 && S % p == 0, VSOM_EINVAL, "patch_embed_bwd: bad shape");
+    VSOM_REQUIRE(ws && ws_bytes >= vsom_patch_embed_bwd_workspace_bytes(B, C, S, p, E), VSOM_EWORKSPACE, "patch_embed_bwd: workspace too small");
+    const int g = S / p, n = g * g, Ntok = n + 1, pd = C * p * p;
+    // dWpe[E, pd] = sum over patch rows of dtokens[row]^T xp[row]; the CLS rows are skipped by the
+    // reduction-row map of the k-strided A operand.
+    const int M = B * n;
+    int rc = linear_bwd_weight_impl(dtokens, E, xp_ws, pd, dWpe, dbpe, M, E, pd, n, Ntok, 1, ws, ws_bytes, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(cls_grad_kernel, dim3(cdiv(E, 256)), dim3(256), 0, stream, dtokens, dcls_token, B, Ntok, E);
+    VSOM_LAUNCH_CHECK("cls_grad_kernel");
+}
+
+size_t vsom_l1_unpatchify_workspace_bytes(int B, int C, int S, int p) {
+    if (B <= 0 || C <= 0 || S <= 0 || p <= 0) return 0;
+    const int g = S / p;
+    return (size_t)l1_blocks((long)B * (g * g + 1) * p * p * C) * sizeof(float);
+}
+
+int vsom_l1_unpatchify(const float* pred, const float* img, float* recon, float* loss_sum, float* dpred,
+                       float grad_scale, int B, int C, int S, int p, void* ws, size_t ws_bytes,
+                       vsom_stream_t stream) {
+    VSOM_REQUIRE(pred && img && loss_sum, VSOM_EINVAL, "l1_unpatchify: null pointer");
+    VSOM_REQUIRE(B > 0 && C > 0 && S > 0 && p > 0 && S % p == 0, VSOM_EINVAL, "l1_unpatchify: bad shape");
+    VSOM_REQUIRE(ws && ws_bytes >= vsom_l1_unpatchify_workspace_bytes(B, C, S, p), VSOM_EWORKSPACE, "l1_unpatchify: workspace too small");
+    const int g = S / p;
+    const long total = (long)B * (g * g + 1) * p * p * C;
+    const int nblk = l1_blocks(total);
+    float* part = static_cast<float*>(ws);
+    hipLaunchKernelGGL(l1_unpatchify_kernel, dim3(nblk), dim3(256), 0, stream, pred, img, recon, part, dpred, grad_scale,
+                       total, C, S, p, g);
+    int rc = hip_status(hipGetLastError(), "l1_unpatchify_kernel");
+    if (rc) return rc;
+    return sum_partials(part, nblk, loss_sum, stream);
+}
+
+size_t vsom_cross_entropy_ls_workspace_bytes(int B) { return B > 0 ? (size_t)B * sizeof(float) : 0; }
+
+int vsom_cross_entropy_ls(const float* logits, const int64_t* y, float smoothing, float* loss_sum, float* dlogits,
+                          float grad_scale, int B, int C, void* ws, size_t ws_bytes, vsom_stream_t stream) {
+    VSOM_REQUIRE(logits && y && loss_sum, VSOM_EINVAL, "cross_entropy_ls: null pointer");
+    VSOM_REQUIRE(B > 0 && C > 0, VSOM_EINVAL, "cross_entropy_ls: bad shape");
+    VSOM_REQUIRE(ws && ws_bytes >= vsom_cross_entropy_ls_workspace_bytes(B), VSOM_EWORKSPACE, "cross_entropy_ls: workspace too small");
+    float* part = static_cast<float*>(ws);
+    hipLaunchKernelGGL(ce_ls_kernel, dim3(cdiv(B, 4)), dim3(256), 0, stream, logits, y, smoothing, part, dlogits,
+                       grad_scale, B, C);
+    int rc = hip_status(hipGetLastError(), "ce_ls_kernel");
+    if (rc) return rc;
+    return sum_partials(part, B, loss_sum, stream);
+}
+
+int vsom_adamw_step(float* p, const float* g, float* m, float* v, const float* wd_per_chunk, long n, float lr,
+                    float beta1, float beta2, float eps, int step, float grad_scale, int adamw,
+                    vsom_stream_t stream) {
+    VSOM_REQUIRE(p && g && m && v && wd_per_chunk, VSOM_EINVAL, "adamw_step: null pointer");
+    VSOM_REQUIRE(n > 0 && n % 256 == 0, VSOM_EINVAL, "adamw_step: n=%ld must be a positive multiple of 256", n);
+    VSOM_REQUIRE(step >= 1, VSOM_EINVAL, "adamw_step: step must be >= 1");
+    VSOM_REQUIRE(aligned16(p) && aligned16(g) && aligned16(m) && aligned16(v), VSOM_EALIGN, "adamw_step: 16-byte alignment required");
+    const double bc1 = 1.0 - pow((double)beta1, step);
+    const double bc2 = 1.0 - pow((double)beta2, step);
+    const float step_size = (float)((double)lr / bc1);
+    const float inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
+    const long n4 = n / 4;
+    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n4, 256, 8192)), dim3(256), 0, stream, p, g, m, v, wd_per_chunk, n4,
+                       lr, beta1, beta2, eps, step_size, inv_bc2_sqrt, grad_scale, adamw);
+    VSOM_LAUNCH_CHECK("adamw_kernel");
+}
+
+}  // extern "C"

@@ -1,0 +1,238 @@
+// SOM layer kernels: row norms, BMU distance pass (+ first-argmin), neighbourhood weights /
+// loss / backward coefficients, prototype ("neighbourhood accumulator") and input gradients.
+#include "gemm_f32.h"
+
+namespace vsom {
+
+// ------------------------------------------------------------------ 1 / max(||row||, eps)
+// one wave per row, 16-byte loads; rows are 12-49k floats at the BASELINE configs
+__global__ __launch_bounds__(256) void row_inv_norm_kernel(const float* __restrict__ X, long ldx, int rows,
+                                                           int cols, float eps, float* __restrict__ out,
+                                                           int vec) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* x = X + (long)row * ldx;
+    float s = 0.f;
+    if (vec) {
+        const int n4 = cols >> 2;
+        for (int i = lane; i < n4; i += 64) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(x + 4 * i);
+            s = fmaf(v[0], v[0], s); s = fmaf(v[1], v[1], s); s = fmaf(v[2], v[2], s); s = fmaf(v[3], v[3], s);
+        }
+        for (int i = (n4 << 2) + lane; i < cols; i += 64) s = fmaf(x[i], x[i], s);
+    } else {
+        for (int i = lane; i < cols; i += 64) s = fmaf(x[i], x[i], s);
+    }
+    s = wave_sum(s);
+    if (lane == 0) out[row] = 1.0f / fmaxf(sqrtf(s), eps);
+}
+
+// ------------------------------------------------------------------ BMU finalize
+// dist[i,k] = 1 - (sum_s slab[s][i,k]) * inv_nx[i] * inv_nw[k];  bmu[i] = first argmin_k.
+// One workgroup per sample row; (value, index) reduction with lowest-index tie-break, so
+// bmu is EXACTLY torch.argmin of the distances this kernel writes.
+__global__ __launch_bounds__(256) void bmu_finalize_kernel(const float* __restrict__ slab, long slab_stride,
+                                                           int nslabs, const float* __restrict__ inv_nx,
+                                                           const float* __restrict__ inv_nw,
+                                                           float* __restrict__ dist, int64_t* __restrict__ bmu,
+                                                           int K) {
+    const int i = blockIdx.x;
+    const float rx = inv_nx[i];
+    float best = INFINITY;
+    int bidx = 0x7fffffff;
+    for (int k = threadIdx.x; k < K; k += 256) {
+        float dot = 0.f;
+        for (int s = 0; s < nslabs; ++s) dot += slab[(long)s * slab_stride + (long)i * K + k];
+        const float d = 1.0f - dot * rx * inv_nw[k];
+        if (dist) dist[(long)i * K + k] = d;
+        if (d < best || (d == best && k < bidx)) { best = d; bidx = k; }
+    }
+    // NaN distances never win (d < best is false) unless every entry is NaN -> index 0x7fffffff
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bidx, o, 64);
+        if (ob < best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
+    }
+    __shared__ float sb[4];
+    __shared__ int si[4];
+    if ((threadIdx.x & 63) == 0) { sb[threadIdx.x >> 6] = best; si[threadIdx.x >> 6] = bidx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w)
+            if (sb[w] < best || (sb[w] == best && si[w] < bidx)) { best = sb[w]; bidx = si[w]; }
+        bmu[i] = (bidx == 0x7fffffff) ? 0 : (int64_t)bidx;
+    }
+}
+
+static int bmu_splits(int B, int K, int L) {
+    const int BN = 128;
+    const int tiles = cdiv(B, 128) * cdiv(K, BN);
+    const int ktiles = cdiv(L, 32);
+    int s = cdiv(768, tiles);               // ~3 workgroups per CU
+    if (s > ktiles / 8) s = ktiles / 8;     // keep >= 8 k-tiles (256 deep) per split
+    if (s > 32) s = 32;
+    if (s < 1) s = 1;
+    const int per = cdiv(ktiles, s);
+    return cdiv(ktiles, per);
+}
+
+// ------------------------------------------------------------------ neighbourhood / loss / coefficients
+// block per sample row i
+__global__ __launch_bounds__(256) void som_neigh_row_kernel(const float* __restrict__ dist,
+                                                            const int64_t* __restrict__ bmu,
+                                                            const float* __restrict__ grid, float inv_2T2,
+                                                            const float* __restrict__ inv_nx,
+                                                            const float* __restrict__ inv_nw, float c,
+                                                            float* __restrict__ h_out, float* __restrict__ coef,
+                                                            float* __restrict__ row_dot,
+                                                            float* __restrict__ loss_part, int K) {
+    const int i = blockIdx.x;
+    const int64_t b = bmu[i];
+    const float by = grid[2 * b], bx = grid[2 * b + 1];
+    const float rx = inv_nx ? inv_nx[i] : 0.f;
+    float lsum = 0.f, dsum = 0.f;
+    for (int k = threadIdx.x; k < K; k += 256) {
+        const float dy = grid[2 * k] - by, dx = grid[2 * k + 1] - bx;
+        const float h = expf(-(dy * dy + dx * dx) * inv_2T2);
+        const float d = dist[(long)i * K + k];
+        if (h_out) h_out[(long)i * K + k] = h;
+        if (coef) coef[(long)i * K + k] = -c * h * rx * inv_nw[k];
+        lsum = fmaf(h, d, lsum);
+        dsum = fmaf(h, 1.0f - d, dsum);
+    }
+    lsum = wave_sum(lsum);
+    dsum = wave_sum(dsum);
+    __shared__ float s1[4], s2[4];
+    if ((threadIdx.x & 63) == 0) { s1[threadIdx.x >> 6] = lsum; s2[threadIdx.x >> 6] = dsum; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        loss_part[i] = (s1[0] + s1[1]) + (s1[2] + s1[3]);
+        if (row_dot) row_dot[i] = c * rx * rx * ((s2[0] + s2[1]) + (s2[2] + s2[3]));
+    }
+}
+// thread per prototype column k, fixed-order loop over the B sample rows
+__global__ __launch_bounds__(256) void som_neigh_col_kernel(const float* __restrict__ dist,
+                                                            const int64_t* __restrict__ bmu,
+                                                            const float* __restrict__ grid, float inv_2T2,
+                                                            const float* __restrict__ inv_nw, float c,
+                                                            float* __restrict__ col_dot, int B, int K) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= K) return;
+    const float gy = grid[2 * k], gx = grid[2 * k + 1];
+    float s = 0.f;
+    for (int i = 0; i < B; ++i) {
+        const int64_t b = bmu[i];
+        const float dy = gy - grid[2 * b], dx = gx - grid[2 * b + 1];
+        const float h = expf(-(dy * dy + dx * dx) * inv_2T2);
+        s = fmaf(h, 1.0f - dist[(long)i * K + k], s);
+    }
+    const float rw = inv_nw[k];
+    col_dot[k] = c * rw * rw * s;
+}
+// deterministic sum of n partials into out[0] (single workgroup)
+__global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restrict__ part, int n,
+                                                           float* __restrict__ out) {
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) s += part[i];
+    s = wave_sum(s);
+    __shared__ float sh[4];
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+int sum_partials(const float* part, int n, float* out, hipStream_t stream) {
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, stream, part, n, out);
+    VSOM_LAUNCH_CHECK("sum_partials_kernel");
+}
+
+}  // namespace vsom
+
+using namespace vsom;
+
+extern "C" {
+
+int vsom_row_inv_norm(const float* X, long ldx, int rows, int cols, float eps, float* inv_norm,
+                      vsom_stream_t stream) {
+    VSOM_REQUIRE(X && inv_norm && rows > 0 && cols > 0 && ldx >= cols, VSOM_EINVAL, "row_inv_norm: bad arguments");
+    const int vec = aligned16(X) && (ldx % 4 == 0);
+    hipLaunchKernelGGL(row_inv_norm_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, stream, X, ldx, rows, cols, eps,
+                       inv_norm, vec);
+    VSOM_LAUNCH_CHECK("row_inv_norm_kernel");
+}
+
+size_t vsom_bmu_cosine_workspace_bytes(int B, int K, int L) {
+    if (B <= 0 || K <= 0 || L <= 0) return 0;
+    return (size_t)bmu_splits(B, K, L) * (size_t)B * K * sizeof(float);
+}
+
+int vsom_bmu_cosine_fwd(const float* X, long ldx, const float* W, const float* inv_nx, const float* inv_nw,
+                        float* dist, int64_t* bmu, int B, int K, int L, void* ws, size_t ws_bytes,
+                        vsom_stream_t stream) {
+    VSOM_REQUIRE(X && W && inv_nx && inv_nw && bmu, VSOM_EINVAL, "bmu_cosine_fwd: null pointer");
+    VSOM_REQUIRE(B > 0 && K > 0 && L > 0 && ldx >= L, VSOM_EINVAL, "bmu_cosine_fwd: bad shape B=%d K=%d L=%d ldx=%ld", B, K, L, ldx);
+    VSOM_REQUIRE(ws && ws_bytes >= vsom_bmu_cosine_workspace_bytes(B, K, L), VSOM_EWORKSPACE,
+                 "bmu_cosine_fwd: workspace too small");
+    const int splits = bmu_splits(B, K, L);
+    GemmP g = {};
+    g.A = X; g.lda = ldx; g.B = W; g.ldb = L;
+    g.M = B; g.N = K; g.K = L;
+    g.slab = static_cast<float*>(ws); g.slab_stride = (long)B * K;
+    int rc = launch_gemm(true, true, EPI_SLAB, g, splits, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(bmu_finalize_kernel, dim3(B), dim3(256), 0, stream, (const float*)ws, (long)B * K, splits,
+                       inv_nx, inv_nw, dist, bmu, K);
+    VSOM_LAUNCH_CHECK("bmu_finalize_kernel");
+}
+
+size_t vsom_som_neigh_workspace_bytes(int B, int K) { (void)K; return B > 0 ? (size_t)B * sizeof(float) : 0; }
+
+int vsom_som_neigh_loss(const float* dist, const int64_t* bmu, const float* grid, float T, const float* inv_nx,
+                        const float* inv_nw, float grad_scale, float* h, float* loss_sum, float* coef,
+                        float* row_dot, float* col_dot, int B, int K, void* ws, size_t ws_bytes,
+                        vsom_stream_t stream) {
+    VSOM_REQUIRE(dist && bmu && grid && loss_sum, VSOM_EINVAL, "som_neigh_loss: null pointer");
+    VSOM_REQUIRE(B > 0 && K > 0 && T > 0.f, VSOM_EINVAL, "som_neigh_loss: bad shape/temperature");
+    VSOM_REQUIRE(ws && ws_bytes >= vsom_som_neigh_workspace_bytes(B, K), VSOM_EWORKSPACE, "som_neigh_loss: workspace too small");
+    const bool bwd = coef || row_dot || col_dot;
+    VSOM_REQUIRE(!bwd || (coef && row_dot && col_dot && inv_nx && inv_nw), VSOM_EINVAL,
+                 "som_neigh_loss: backward outputs need coef, row_dot, col_dot, inv_nx and inv_nw together");
+    const float inv_2T2 = (float)(1.0 / (2.0 * (double)T * (double)T));
+    float* part = static_cast<float*>(ws);
+    hipLaunchKernelGGL(som_neigh_row_kernel, dim3(B), dim3(256), 0, stream, dist, bmu, grid, inv_2T2, inv_nx, inv_nw,
+                       grad_scale, h, coef, row_dot, part, K);
+    int rc = hip_status(hipGetLastError(), "som_neigh_row_kernel");
+    if (rc) return rc;
+    rc = sum_partials(part, B, loss_sum, stream);
+    if (rc) return rc;
+    if (bwd) {
+        hipLaunchKernelGGL(som_neigh_col_kernel, dim3(cdiv(K, 256)), dim3(256), 0, stream, dist, bmu, grid, inv_2T2,
+                           inv_nw, grad_scale, col_dot, B, K);
+        rc = hip_status(hipGetLastError(), "som_neigh_col_kernel");
+    }
+    return rc;
+}
+
+int vsom_som_bwd(const float* X, long ldx, const float* W, const float* coef, const float* row_dot,
+                 const float* col_dot, float* gW, float* gX, long ldgx, int accumulate_gx, int B, int K, int L,
+                 vsom_stream_t stream) {
+    VSOM_REQUIRE(X && W && coef && row_dot && col_dot && gW && gX, VSOM_EINVAL, "som_bwd: null pointer");
+    VSOM_REQUIRE(B > 0 && K > 0 && L > 0 && ldx >= L && ldgx >= L, VSOM_EINVAL, "som_bwd: bad shape");
+    // gW[K,L] = coef^T[K,B] X[B,L] + col_dot[k] W[k,:]      (reduction over the batch)
+    GemmP g = {};
+    g.A = coef; g.lda = K; g.B = X; g.ldb = ldx; g.C = gW; g.ldc = L;
+    g.M = K; g.N = L; g.K = B;
+    g.rowscale = col_dot; g.R = W; g.ldr = L; g.accumulate = 0;
+    int rc = launch_gemm(false, false, EPI_ROWAXPY, g, 1, stream);
+    if (rc) return rc;
+    // gX[B,L] (+)= coef[B,K] W[K,L] + row_dot[i] X[i,:]     (reduction over the prototypes)
+    GemmP q = {};
+    q.A = coef; q.lda = K; q.B = W; q.ldb = L; q.C = gX; q.ldc = ldgx;
+    q.M = B; q.N = L; q.K = K;
+    q.rowscale = row_dot; q.R = X; q.ldr = ldx; q.accumulate = accumulate_gx;
+    return launch_gemm(true, false, EPI_ROWAXPY, q, 1, stream);
+}
+
+}  // extern "C"

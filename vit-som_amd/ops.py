@@ -1,0 +1,224 @@
+"""Tensor-level wrappers over the C-ABI (one per entry point of include/vitsom_hip.h).
+
+Every wrapper validates device / dtype / inner-stride, passes raw device pointers, row strides
+and torch's current HIP stream, and raises ``VsomError`` on a non-zero status.  Nothing here
+computes: there is no eager fallback.
+"""
+from typing import Optional
+
+import torch
+
+from ._lib import check, lib, ptr, stream
+
+_scratch = {}
+
+
+def scratch(nbytes: int, device) -> torch.Tensor:
+    """Grow-only per-device byte scratch (stream-ordered reuse; 256-byte aligned by the allocator)."""
+    key = torch.device(device).index or 0
+    buf = _scratch.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _scratch[key] = buf
+    return buf
+
+
+def _f32(t: torch.Tensor, name: str, inner_contig: bool = True):
+    if not t.is_cuda:
+        raise ValueError(f"{name}: expected a HIP device tensor (vit_som_amd has no CPU path)")
+    if t.dtype != torch.float32:
+        raise ValueError(f"{name}: expected float32, got {t.dtype}")
+    if inner_contig and t.dim() >= 1 and t.numel() > 0 and t.stride(-1) != 1:
+        raise ValueError(f"{name}: innermost stride must be 1")
+    return t
+
+
+def _rows(t: torch.Tensor) -> int:
+    return t.stride(0) if t.dim() == 2 and t.shape[0] > 1 else t.shape[-1]
+
+
+# ---------------------------------------------------------------- linear
+def linear_fwd(x, W, bias, out):
+    M, K = x.shape
+    N = W.shape[0]
+    _f32(x, "x"); _f32(W, "W"); _f32(out, "out")
+    assert W.shape[1] == K and W.is_contiguous() and out.shape == (M, N)
+    check(lib.vsom_linear_fwd(ptr(x), _rows(x), ptr(W), ptr(bias), ptr(out), _rows(out), M, N, K, stream()), "vsom_linear_fwd")
+    return out
+
+
+def linear_gelu_fwd(x, W, bias, pre, act):
+    M, K = x.shape
+    N = W.shape[0]
+    _f32(x, "x"); _f32(W, "W")
+    assert W.is_contiguous() and pre.is_contiguous() and act.is_contiguous() and pre.shape == (M, N) == act.shape
+    check(lib.vsom_linear_gelu_fwd(ptr(x), _rows(x), ptr(W), ptr(bias), ptr(pre), ptr(act), M, N, K, stream()), "vsom_linear_gelu_fwd")
+    return pre, act
+
+
+def linear_residual_fwd(x, W, bias, R, r_mod, out):
+    M, K = x.shape
+    N = W.shape[0]
+    _f32(x, "x"); _f32(W, "W"); _f32(R, "R"); _f32(out, "out")
+    assert W.is_contiguous() and out.shape == (M, N) and R.shape[-1] == N
+    check(lib.vsom_linear_residual_fwd(ptr(x), _rows(x), ptr(W), ptr(bias), ptr(R), _rows(R), int(r_mod), ptr(out),
+                                       _rows(out), M, N, K, stream()), "vsom_linear_residual_fwd")
+    return out
+
+
+def linear_bwd_input(dy, W, dx, accumulate=False, gelu_pre=None):
+    M, N = dy.shape
+    K = W.shape[1]
+    _f32(dy, "dy"); _f32(W, "W"); _f32(dx, "dx")
+    assert W.shape[0] == N and W.is_contiguous() and dx.shape == (M, K)
+    if gelu_pre is not None:
+        assert gelu_pre.is_contiguous() and gelu_pre.shape == (M, K)
+    check(lib.vsom_linear_bwd_input(ptr(dy), _rows(dy), ptr(W), ptr(dx), _rows(dx), M, N, K, int(accumulate),
+                                    ptr(gelu_pre), stream()), "vsom_linear_bwd_input")
+    return dx
+
+
+def linear_bwd_weight(dy, x, dW, db):
+    M, N = dy.shape
+    K = x.shape[1]
+    _f32(dy, "dy"); _f32(x, "x"); _f32(dW, "dW")
+    assert x.shape[0] == M and dW.is_contiguous() and dW.numel() == N * K
+    nbytes = lib.vsom_linear_bwd_weight_workspace_bytes(M, N, K)
+    ws = scratch(nbytes, dy.device)
+    check(lib.vsom_linear_bwd_weight(ptr(dy), _rows(dy), ptr(x), _rows(x), ptr(dW), ptr(db), M, N, K, ptr(ws), ws.numel(),
+                                     stream()), "vsom_linear_bwd_weight")
+    return dW, db
+
+
+# ---------------------------------------------------------------- patch embedding
+def patch_embed_fwd(img, Wpe, bpe, pos, cls_token, tokens, xp_ws, p):
+    B, Cc, S, _ = img.shape
+    E = Wpe.shape[0]
+    for n_, t in (("img", img), ("Wpe", Wpe), ("tokens", tokens), ("xp_ws", xp_ws)):
+        _f32(t, n_)
+        assert t.is_contiguous(), n_
+    check(lib.vsom_patch_embed_fwd(ptr(img), ptr(Wpe), ptr(bpe), ptr(pos), ptr(cls_token), ptr(tokens), ptr(xp_ws), B, Cc, S,
+                                   p, E, stream()), "vsom_patch_embed_fwd")
+    return tokens
+
+
+def patch_embed_bwd(dtokens, xp_ws, dWpe, dbpe, dcls, B, Cc, S, p, E):
+    assert dtokens.is_contiguous() and xp_ws.is_contiguous()
+    nbytes = lib.vsom_patch_embed_bwd_workspace_bytes(B, Cc, S, p, E)
+    ws = scratch(nbytes, dtokens.device)
+    check(lib.vsom_patch_embed_bwd(ptr(dtokens), ptr(xp_ws), ptr(dWpe), ptr(dbpe), ptr(dcls), B, Cc, S, p, E, ptr(ws),
+                                   ws.numel(), stream()), "vsom_patch_embed_bwd")
+
+
+# ---------------------------------------------------------------- layernorm
+def layernorm_fwd(x, gamma, beta, y, mean, rstd, eps=1e-6):
+    rows, cols = x.shape
+    assert x.is_contiguous() and y.is_contiguous()
+    _f32(x, "x")
+    check(lib.vsom_layernorm_fwd(ptr(x), ptr(gamma), ptr(beta), ptr(y), ptr(mean), ptr(rstd), rows, cols, float(eps), stream()),
+          "vsom_layernorm_fwd")
+    return y
+
+
+def layernorm_bwd(dy, x, mean, rstd, gamma, resid, dx, dgamma, dbeta):
+    rows, cols = x.shape
+    assert dy.is_contiguous() and x.is_contiguous() and dx.is_contiguous() and (resid is None or resid.is_contiguous())
+    nbytes = lib.vsom_layernorm_bwd_workspace_bytes(rows, cols)
+    ws = scratch(nbytes, x.device)
+    check(lib.vsom_layernorm_bwd(ptr(dy), ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(resid), ptr(dx), ptr(dgamma),
+                                 ptr(dbeta), rows, cols, ptr(ws), ws.numel(), stream()), "vsom_layernorm_bwd")
+    return dx
+
+
+# ---------------------------------------------------------------- attention
+def attention_fwd(qkv, out, lse, B, N, H, hd):
+    assert qkv.is_contiguous() and out.is_contiguous() and lse.is_contiguous()
+    _f32(qkv, "qkv")
+    check(lib.vsom_attention_fwd(ptr(qkv), ptr(out), ptr(lse), B, N, H, hd, stream()), "vsom_attention_fwd")
+    return out
+
+
+def attention_bwd(qkv, out, dout, lse, dqkv, delta, B, N, H, hd):
+    assert all(t.is_contiguous() for t in (qkv, out, dout, lse, dqkv, delta))
+    check(lib.vsom_attention_bwd(ptr(qkv), ptr(out), ptr(dout), ptr(lse), ptr(dqkv), ptr(delta), B, N, H, hd, stream()),
+          "vsom_attention_bwd")
+    return dqkv
+
+
+# ---------------------------------------------------------------- SOM
+def row_inv_norm(x, out, eps=1e-12):
+    rows, cols = x.shape
+    _f32(x, "x")
+    check(lib.vsom_row_inv_norm(ptr(x), _rows(x), rows, cols, float(eps), ptr(out), stream()), "vsom_row_inv_norm")
+    return out
+
+
+def bmu_cosine_fwd(x, W, inv_nx, inv_nw, dist: Optional[torch.Tensor], bmu):
+    B, L = x.shape
+    K = W.shape[0]
+    _f32(x, "x"); _f32(W, "W")
+    assert W.is_contiguous() and W.shape[1] == L and bmu.dtype == torch.int64 and (dist is None or dist.is_contiguous())
+    nbytes = lib.vsom_bmu_cosine_workspace_bytes(B, K, L)
+    ws = scratch(nbytes, x.device)
+    check(lib.vsom_bmu_cosine_fwd(ptr(x), _rows(x), ptr(W), ptr(inv_nx), ptr(inv_nw), ptr(dist), ptr(bmu), B, K, L, ptr(ws),
+                                  ws.numel(), stream()), "vsom_bmu_cosine_fwd")
+    return dist, bmu
+
+
+def som_neigh_loss(dist, bmu, grid, T, loss_sum, h=None, inv_nx=None, inv_nw=None, grad_scale=0.0, coef=None,
+                   row_dot=None, col_dot=None):
+    B, K = dist.shape
+    assert dist.is_contiguous() and grid.is_contiguous() and bmu.dtype == torch.int64
+    nbytes = lib.vsom_som_neigh_workspace_bytes(B, K)
+    ws = scratch(nbytes, dist.device)
+    check(lib.vsom_som_neigh_loss(ptr(dist), ptr(bmu), ptr(grid), float(T), ptr(inv_nx), ptr(inv_nw), float(grad_scale),
+                                  ptr(h), ptr(loss_sum), ptr(coef), ptr(row_dot), ptr(col_dot), B, K, ptr(ws), ws.numel(),
+                                  stream()), "vsom_som_neigh_loss")
+    return loss_sum
+
+
+def som_bwd(x, W, coef, row_dot, col_dot, gW, gX, accumulate_gx=True):
+    B, L = x.shape
+    K = W.shape[0]
+    assert W.is_contiguous() and coef.is_contiguous() and gW.is_contiguous()
+    check(lib.vsom_som_bwd(ptr(x), _rows(x), ptr(W), ptr(coef), ptr(row_dot), ptr(col_dot), ptr(gW), ptr(gX), _rows(gX),
+                           int(accumulate_gx), B, K, L, stream()), "vsom_som_bwd")
+
+
+# ---------------------------------------------------------------- losses
+def l1_unpatchify(pred, img, loss_sum, recon=None, dpred=None, grad_scale=0.0, p=1):
+    B, Cc, S, _ = img.shape
+    assert pred.is_contiguous() and img.is_contiguous()
+    nbytes = lib.vsom_l1_unpatchify_workspace_bytes(B, Cc, S, p)
+    ws = scratch(nbytes, img.device)
+    check(lib.vsom_l1_unpatchify(ptr(pred), ptr(img), ptr(recon), ptr(loss_sum), ptr(dpred), float(grad_scale), B, Cc, S, p,
+                                 ptr(ws), ws.numel(), stream()), "vsom_l1_unpatchify")
+    return loss_sum
+
+
+def cross_entropy_ls(logits, y, smoothing, loss_sum, dlogits=None, grad_scale=0.0):
+    B, Cn = logits.shape
+    assert logits.is_contiguous() and y.dtype == torch.int64
+    nbytes = lib.vsom_cross_entropy_ls_workspace_bytes(B)
+    ws = scratch(nbytes, logits.device)
+    check(lib.vsom_cross_entropy_ls(ptr(logits), ptr(y), float(smoothing), ptr(loss_sum), ptr(dlogits), float(grad_scale), B,
+                                    Cn, ptr(ws), ws.numel(), stream()), "vsom_cross_entropy_ls")
+    return loss_sum
+
+
+# ---------------------------------------------------------------- optimiser / utilities
+def adamw_step(p, g, m, v, wd_chunk, lr, beta1, beta2, eps, step, grad_scale=1.0, adamw=True):
+    n = p.numel()
+    check(lib.vsom_adamw_step(ptr(p), ptr(g), ptr(m), ptr(v), ptr(wd_chunk), n, float(lr), float(beta1), float(beta2),
+                              float(eps), int(step), float(grad_scale), int(adamw), stream()), "vsom_adamw_step")
+
+
+def fill(t, value):
+    check(lib.vsom_fill(ptr(t), t.numel(), float(value), stream()), "vsom_fill")
+    return t
+
+
+def reduce_slabs(slabs, out):
+    nslabs, n = slabs.shape
+    check(lib.vsom_reduce_slabs(ptr(slabs), slabs.stride(0), nslabs, ptr(out), n, stream()), "vsom_reduce_slabs")
+    return out
