@@ -1,0 +1,162 @@
+"""ViT-SOM training-step benchmark (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one full optimisation step of the hot path on one synthetic batch already resident
+in HBM: forward (ViT autoencoder + SOM BMU pass) + losses + backward + gradient all-reduce (RCCL,
+N > 1) + fused AdamW.  Workload = BASELINE config c3: CIFAR-10 shapes, 40x40 SOM, per-GPU batch
+512 (weak scaling: the reference's batch_size is per rank).  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense f32 MFMA peak (no xf32 on gfx950)
+
+
+def c3_config(batch):
+    return {
+        "hyperparameters": {
+            "model_arch": "vit_som", "total_epochs": 500, "batch_size": batch, "gamma": 0.01,
+            "som": {"map_size": [40, 40], "Tmax": 4, "Tmin": 0.1, "distance_fcn": "cosine", "topology": "square",
+                    "use_reduced": False},
+            "vit": {"patch_size": 4, "emb_dim": 192, "depth": 12, "dec_emb_dim": 96, "dec_depth": 2, "heads": 3,
+                    "mlp_ratio": 4, "qkv_bias": True, "qk_norm": False, "proj_drop": 0, "attn_drop": 0, "drop_path": 0.1,
+                    "global_pool": False},
+            "optimizer": {"type": "adamw", "lr": 0.0005, "min_lr": 0.000001, "beta_1": 0.9, "beta_2": 0.999,
+                          "scheduler": "cosine_annealing", "warmup_epochs": 25, "weight_decay": 0.05, "layer_decay": 0.75,
+                          "smoothing": 0.1},
+        },
+        "data": {"dataset": "synthetic-cifar10", "num_classes": 0, "num_channels": 3, "input_size": 32, "num_workers": 0},
+    }
+
+
+def cpu_baseline(seconds_budget=25.0):
+    """The CPU oracle (oracle/vitsom_oracle.py: fwd + bwd + AdamW, pure torch CPU ops, fp32
+    'highest') timed on the host cores on a bounded sample of the same workload."""
+    from oracle import vitsom_oracle as O
+    Bc = 64
+    cfg = c3_config(Bc)
+    torch.set_float32_matmul_precision("highest")
+    step = O.CPUStep(cfg, seed=0)
+    x, y = O.synthetic_batch(step.d, Bc, seed=0)
+    n_train, est = 50000, 100000
+    t0 = time.perf_counter()
+    step.step(x, y, n_train, est)                       # warm-up
+    warm = time.perf_counter() - t0
+    nsteps = max(1, min(8, int(seconds_budget / max(warm, 1e-3)) - 1))
+    t0 = time.perf_counter()
+    for _ in range(nsteps):
+        step.step(x, y, n_train, est)
+    dt = time.perf_counter() - t0
+    return {"value": round(Bc * nsteps / dt, 2), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{nsteps} step(s) of the same c3 workload at batch {Bc} (fwd+bwd+AdamW, fp32 'highest') after 1 warm-up"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=512, help="per-GPU batch (BASELINE c3: 512)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # nccl == RCCL on ROCm
+
+    import vit_som_amd
+    from vit_som_amd import ops
+
+    B = args.batch
+    cfg = c3_config(B)
+    torch.manual_seed(0)                                # identical replicas on every rank
+    model = vit_som_amd.ViTSOM(cfg, device=dev)
+    model.set_distributed(world, rank)
+    n_train = 50000
+    model.set_schedule(n_train, (n_train // (B * world)) * cfg["hyperparameters"]["total_epochs"])
+    model._it = 1000                                    # mid-ramp: gamma_t > 0 so the SOM gradients are live
+    (opt,), _ = model.configure_optimizers()
+    g = torch.Generator().manual_seed(1234 + rank)      # a different shard of synthetic images per rank
+    x = torch.randn(B, 3, 32, 32, generator=g).to(dev)
+    y = torch.zeros(B, dtype=torch.int64, device=dev)
+
+    def step():
+        loss = model.train_step_fused(x, y)
+        opt.step()
+        return loss
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    ops.enable_timer("bmu_cosine_dots")
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    bmu_ms, bmu_calls = ops.timer_ms("bmu_cosine_dots")
+    ops.disable_timers()
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t)
+    final_loss = float(loss)
+
+    if rank == 0:
+        K, L = 1600, 12288
+        bmu_bytes = 4.0 * (B * L + K * L + B * K)       # 107.1 MB at B=512
+        bmu_flops = 2.0 * B * L * K                     # 20.13 GFLOP
+        t_s = bmu_ms * 1e-3
+        out = {
+            "metric": "images/sec/node ViT-SOM 40x40 CIFAR-10 bs512 (training step: fwd+bwd+all-reduce+AdamW)",
+            "value": round(world * B * args.steps / dt, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "c3: vit_som CIFAR-10 shapes (3x32x32, patch 4, E=192, 3 heads, depth 12 + 2-layer "
+                                   "decoder), 40x40 cosine SOM on the flattened patch tokens (L=12288), clustering loss "
+                                   "L1(recon)+gamma*SOM, AdamW, random-init weights",
+                       "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}",
+                       "final_loss": round(final_loss, 6)},
+            "roofline": {"kernel": "gemm_f32_kernel<1,1,2,2,2,2,6> (BMU distance pass: X[B,L] . W[K,L]^T, split over L)",
+                         "bound": "mfma", "achieved": round(bmu_flops / t_s / 1e12, 3), "peak": F32_MFMA_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(bmu_flops / t_s / 1e12 / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                         "avg_launch_ms": round(bmu_ms, 4), "launches_timed": bmu_calls,
+                         "algorithmic_flops": bmu_flops, "algorithmic_bytes": bmu_bytes,
+                         "hbm_view": {"achieved_GBps": round(bmu_bytes / t_s / 1e9, 1), "peak_GBps": HBM_PEAK_GBS,
+                                      "frac": round(bmu_bytes / t_s / 1e9 / HBM_PEAK_GBS, 4)}},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -113,6 +113,13 @@ size_t vsom_bmu_cosine_workspace_bytes(int B, int K, int L);
 int vsom_bmu_cosine_fwd(const float* X, long ldx, const float* W, const float* inv_nx,
                         const float* inv_nw, float* dist, int64_t* bmu, int B, int K, int L, void* ws,
                         size_t ws_bytes, vsom_stream_t stream);
+/* The two halves of vsom_bmu_cosine_fwd, callable separately (bench.py times the distance pass
+ * alone): _dots = the [B,L]x[L,K] contraction, split over L into fp32 partial slabs in ws;
+ * _finalize = slab sum, 1 - dot * inv_nx * inv_nw, first-argmin. */
+int vsom_bmu_cosine_dots(const float* X, long ldx, const float* W, int B, int K, int L, void* ws,
+                         size_t ws_bytes, vsom_stream_t stream);
+int vsom_bmu_cosine_finalize(const void* ws, size_t ws_bytes, const float* inv_nx, const float* inv_nw,
+                             float* dist, int64_t* bmu, int B, int K, int L, vsom_stream_t stream);
 /* Neighbourhood weights + SOM loss + backward coefficients in one pass over [B,K]:
  *   h_ik = exp(-||g_k - g_bmu(i)||^2 / (2 T^2))              compute_weights, som_layer.py:144-152
  *   loss_sum[0] = sum_ik h_ik d_ik   (caller divides by B*K)  som_loss, som_layer.py:137-142

@@ -1,0 +1,212 @@
+"""End-to-end GPU parity of the ViTSOM host class (all HIP kernels chained) against
+(1) golden vectors produced by the reference itself and (2) the CPU oracle at larger shapes."""
+import copy
+
+import pytest
+import torch
+
+from helpers import REF_CASES, golden_params, load_golden, rel_err
+
+pytestmark = pytest.mark.gpu
+COSINE_CASES = [c for c in REF_CASES if "euclid" not in c]
+DEV = "cuda"
+
+
+def build(cfg, params=None):
+    import vit_som_amd
+    m = vit_som_amd.ViTSOM(copy.deepcopy(cfg), device=DEV)
+    if params is not None:
+        m.load_state_dict(params)
+    return m
+
+
+def bmu_ok(bmu, dist_ref, eps=2e-6):
+    """exact outside fp32 near-ties of the reference distances (SURVEY hard part 3)."""
+    ref = dist_ref.argmin(1)
+    srt = dist_ref.sort(1).values
+    gap = srt[:, 1] - srt[:, 0]
+    chosen = dist_ref.gather(1, bmu.view(-1, 1)).squeeze(1)
+    return bool(((bmu == ref) | ((gap <= eps) & (chosen - srt[:, 0] <= eps))).all())
+
+
+@pytest.mark.parametrize("name", COSINE_CASES)
+def test_forward_matches_reference_golden(name):
+    z, cfg = load_golden(name)
+    m = build(cfg, golden_params(z))
+    x = torch.from_numpy(z["x"]).to(DEV)
+    cls, recon, logits, dist, bmu = m(x)
+    # north_star tolerance: 1e-4 fp32 on logits/outputs; measured ~1e-6
+    assert torch.allclose(cls.cpu(), torch.from_numpy(z["fwd/cls"]), atol=1e-4)
+    assert float((cls.cpu() - torch.from_numpy(z["fwd/cls"])).abs().max()) < 2e-5
+    assert torch.allclose(recon.cpu(), torch.from_numpy(z["fwd/recon"]), atol=2e-5)
+    assert torch.allclose(dist.cpu(), torch.from_numpy(z["fwd/dist"]), atol=1e-5)
+    assert bmu.dtype == torch.int64
+    assert torch.equal(bmu.cpu(), torch.from_numpy(z["fwd/bmu"]))        # BMU indices bit-exact
+    if m.classification:
+        assert torch.allclose(logits.cpu(), torch.from_numpy(z["fwd/logits"]), atol=2e-5)
+    else:
+        assert logits is None
+    # sub-module surface used by tools/evaluation.py
+    c2, p2, r2 = m.vit(x)
+    assert torch.equal(c2, cls) and torch.equal(r2, recon) and p2.shape == (x.shape[0], m.vit.patch_embed.num_patches, m.vit.embed_dim)
+    d2, b2 = m.som_layer(p2)
+    assert torch.equal(b2, bmu) and torch.allclose(d2, dist, atol=1e-6)
+
+
+@pytest.mark.parametrize("name", COSINE_CASES)
+def test_training_step_grads_match_reference_golden(name):
+    z, cfg = load_golden(name)
+    m = build(cfg, golden_params(z))
+    m.set_schedule(int(z["n_train"]), int(z["est_steps"]))
+    assert m._it == int(z["iteration"])
+    x, y = torch.from_numpy(z["x"]).to(DEV), torch.from_numpy(z["y"]).to(DEV)
+    loss = m.training_step((x, y), 0)
+    assert abs(float(loss) - float(z["train/loss"])) < 2e-5
+    assert abs(float(m.som_layer.current_temperature) - float(z["train/T"])) < 1e-6 * float(z["train/T"])
+    loss.backward()
+    for n, p in m.named_parameters():
+        if not p.requires_grad:
+            continue
+        ref = torch.from_numpy(z["grad/" + n])
+        g = p.grad.cpu()
+        assert g.shape == ref.shape
+        # relative (prototype gradients are ~1e-7 in magnitude), 1e-4 bar
+        assert rel_err(g, ref) < 1e-4 or float((g - ref).abs().max()) < 1e-9, (n, rel_err(g, ref))
+    assert int(m.iteration) == int(z["iteration"]) + 1
+
+
+@pytest.mark.parametrize("name", COSINE_CASES)
+def test_three_step_trajectory_matches_reference_golden(name):
+    """reference configure_optimizers() + 3 optimizer steps vs FusedAdamW on the flat arena."""
+    z, cfg = load_golden(name)
+    m = build(cfg, golden_params(z))
+    m.set_schedule(int(z["n_train"]), int(z["est_steps"]))
+    (opt,), (sched,) = m.configure_optimizers()
+    assert abs(opt.param_groups[0]["lr"] - float(z["opt/lr"])) < 1e-12
+    batches = [(z["x"], z["y"]), (z["x1"], z["y1"]), (z["x2"], z["y2"])]
+    for s, (x, y) in enumerate(batches):
+        opt.zero_grad()
+        if s == 1:      # exercise the fused (autograd-free) entry too: same kernels
+            loss = m.train_step_fused(torch.from_numpy(x).to(DEV), torch.from_numpy(y).to(DEV))
+        else:
+            loss = m.training_step((torch.from_numpy(x).to(DEV), torch.from_numpy(y).to(DEV)), s)
+            loss.backward()
+        opt.step()
+        if s == 0:
+            sd = m.state_dict()
+            for k in sd:
+                if ("after1/" + k) in z.files and sd[k].is_floating_point():
+                    assert torch.allclose(sd[k].cpu(), torch.from_numpy(z["after1/" + k]), atol=2e-6), k
+        else:
+            assert abs(float(loss) - float(z[f"train/loss{s}"])) < 5e-5
+    sd = m.state_dict()
+    for k in sd:
+        if sd[k].is_floating_point():
+            assert torch.allclose(sd[k].cpu(), torch.from_numpy(z["after3/" + k]), atol=1e-5), k
+    assert int(sd["iteration"]) == int(z["after3/iteration"])
+    # validation_step after training (full gamma, last temperature)
+    v = m.validation_step((torch.from_numpy(z["x"]).to(DEV), torch.from_numpy(z["y"]).to(DEV)), 0)
+    assert abs(float(v) - float(z["val/loss"])) < 5e-5
+
+
+def cifar_like_cfg(num_classes, map_size, B, depth=3):
+    from oracle.gen_golden import make_config
+    return make_config(3, 32, 4, 192, depth, 3, 96, 2, map_size, num_classes, B, gamma=0.01, Tmax=4.0, Tmin=0.1)
+
+
+@pytest.mark.parametrize("num_classes,map_size", [(0, (24, 24)), (10, (4, 4))])
+def test_cifar_shapes_against_oracle(num_classes, map_size):
+    """Real CIFAR-10 layer shapes (E=192, 3 heads, N=65, L=12288), reduced depth/batch so the CPU
+    oracle finishes in seconds; forward outputs, loss and every gradient."""
+    from oracle import vitsom_oracle as O
+    B = 16
+    cfg = cifar_like_cfg(num_classes, map_size, B)
+    d = O.Dims(cfg)
+    P = O.init_params(cfg, seed=3)
+    g = torch.Generator().manual_seed(5)
+    for k in O.trainable_keys(P):
+        if P[k].ndim == 1:
+            P[k] = P[k] + 0.05 * torch.randn(P[k].shape, generator=g)
+    x, y = O.synthetic_batch(d, B, seed=1)
+    it, n_train, est = 40, 50000, 200
+    total, parts, G = O.loss_and_grads(P, x, y, d, it, n_train, est)
+    m = build(cfg, P)
+    m._it = it
+    m.set_schedule(n_train, est)
+    cls, recon, logits, dist, bmu = m(x.to(DEV))
+    assert torch.allclose(cls.cpu(), parts["cls"], atol=1e-4)
+    assert torch.allclose(dist.cpu(), parts["dist"], atol=1e-5)
+    assert bmu_ok(bmu.cpu(), parts["dist"].double())
+    assert torch.allclose(recon.cpu(), parts["recon"], atol=1e-4)
+    if num_classes:
+        assert torch.allclose(logits.cpu(), parts["logits"], atol=1e-4)
+    loss = m.training_step((x.to(DEV), y.to(DEV)), 0)
+    assert abs(float(loss) - float(total)) < 1e-4
+    loss.backward()
+    same_bmu = torch.equal(bmu.cpu(), parts["bmu"])
+    for n, p in m.named_parameters():
+        if p.requires_grad:
+            if not same_bmu and n == "som_layer.prototypes":
+                continue
+            e = rel_err(p.grad.cpu(), G[n])
+            assert e < 1e-4 or float((p.grad.cpu() - G[n]).abs().max()) < 1e-9, (n, e)
+
+
+def test_mnist_shapes_against_oracle():
+    """c1 shapes: 28x28x1, p=2 -> N=197, E=16 (hd 8), decoder E=4 (hd 2), 24x24 map."""
+    from oracle import vitsom_oracle as O
+    from oracle.gen_golden import make_config
+    B = 8
+    cfg = make_config(1, 28, 2, 16, 4, 2, 4, 2, (24, 24), 0, B, gamma=0.005, Tmax=20.0, Tmin=0.001)
+    d = O.Dims(cfg)
+    P = O.init_params(cfg, seed=4)
+    x, y = O.synthetic_batch(d, B, seed=2)
+    it, n_train, est = 25, 60000, 100
+    total, parts, G = O.loss_and_grads(P, x, y, d, it, n_train, est)
+    m = build(cfg, P)
+    m._it = it
+    m.set_schedule(n_train, est)
+    loss = m.training_step((x.to(DEV), y.to(DEV)), 0)
+    assert abs(float(loss) - float(total)) < 1e-4
+    s = m._ctx[2]
+    assert torch.allclose(s.dist.cpu(), parts["dist"], atol=1e-5)
+    assert bmu_ok(s.bmu.cpu(), parts["dist"].double())
+    loss.backward()
+    if torch.equal(s.bmu.cpu(), parts["bmu"]):
+        for n, p in m.named_parameters():
+            if p.requires_grad:
+                e = rel_err(p.grad.cpu(), G[n])
+                assert e < 2e-4 or float((p.grad.cpu() - G[n]).abs().max()) < 1e-9, (n, e)
+
+
+def test_steps_are_deterministic():
+    z, cfg = load_golden("ref_cluster_tiny")
+    outs = []
+    for _ in range(2):
+        m = build(cfg, golden_params(z))
+        m.set_schedule(60, 40)
+        x, y = torch.from_numpy(z["x"]).to(DEV), torch.from_numpy(z["y"]).to(DEV)
+        m.train_step_fused(x, y)
+        outs.append(m.arena.grads.clone())
+    assert torch.equal(outs[0], outs[1])
+
+
+def test_use_reduced_cls_token_som():
+    """use_reduced=True: SOM on the CLS token (L = E), vit_som.py:70-71."""
+    from oracle import vitsom_oracle as O
+    z, cfg = load_golden("ref_cls_tiny")
+    cfg = copy.deepcopy(cfg)
+    cfg["hyperparameters"]["som"]["use_reduced"] = True
+    d = O.Dims(cfg)
+    P = O.init_params(cfg, seed=7)
+    x, y = O.synthetic_batch(d, 5, seed=3)
+    total, parts, G = O.loss_and_grads(P, x, y, d, 6, 50, 20)
+    m = build(cfg, P)
+    m._it = 6
+    m.set_schedule(50, 20)
+    loss = m.training_step((x.to(DEV), y.to(DEV)), 0)
+    loss.backward()
+    assert abs(float(loss) - float(total)) < 2e-5
+    for n, p in m.named_parameters():
+        if p.requires_grad:
+            assert rel_err(p.grad.cpu(), G[n]) < 1e-4 or float((p.grad.cpu() - G[n]).abs().max()) < 1e-9, n

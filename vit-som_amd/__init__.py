@@ -2,3 +2,4 @@
 ``ViTSOM`` / ``SOMLayer`` module surface (models/vit_som.py, models/som_layer.py)."""
 from . import _lib  # noqa: F401  (fails loudly when libvitsom_hip.so is absent)
 from . import ops  # noqa: F401
+from .model import FusedAdamW, SOMLayer, ViTAutoencoder, ViTSOM, param_groups_lrd  # noqa: F401,E402

@@ -168,23 +168,37 @@ size_t vsom_bmu_cosine_workspace_bytes(int B, int K, int L) {
     return (size_t)bmu_splits(B, K, L) * (size_t)B * K * sizeof(float);
 }
 
-int vsom_bmu_cosine_fwd(const float* X, long ldx, const float* W, const float* inv_nx, const float* inv_nw,
-                        float* dist, int64_t* bmu, int B, int K, int L, void* ws, size_t ws_bytes,
-                        vsom_stream_t stream) {
-    VSOM_REQUIRE(X && W && inv_nx && inv_nw && bmu, VSOM_EINVAL, "bmu_cosine_fwd: null pointer");
-    VSOM_REQUIRE(B > 0 && K > 0 && L > 0 && ldx >= L, VSOM_EINVAL, "bmu_cosine_fwd: bad shape B=%d K=%d L=%d ldx=%ld", B, K, L, ldx);
+int vsom_bmu_cosine_dots(const float* X, long ldx, const float* W, int B, int K, int L, void* ws, size_t ws_bytes,
+                         vsom_stream_t stream) {
+    VSOM_REQUIRE(X && W, VSOM_EINVAL, "bmu_cosine_dots: null pointer");
+    VSOM_REQUIRE(B > 0 && K > 0 && L > 0 && ldx >= L, VSOM_EINVAL, "bmu_cosine_dots: bad shape B=%d K=%d L=%d ldx=%ld", B, K, L, ldx);
     VSOM_REQUIRE(ws && ws_bytes >= vsom_bmu_cosine_workspace_bytes(B, K, L), VSOM_EWORKSPACE,
-                 "bmu_cosine_fwd: workspace too small");
-    const int splits = bmu_splits(B, K, L);
+                 "bmu_cosine_dots: workspace too small");
     GemmP g = {};
     g.A = X; g.lda = ldx; g.B = W; g.ldb = L;
     g.M = B; g.N = K; g.K = L;
     g.slab = static_cast<float*>(ws); g.slab_stride = (long)B * K;
-    int rc = launch_gemm(true, true, EPI_SLAB, g, splits, stream);
-    if (rc) return rc;
-    hipLaunchKernelGGL(bmu_finalize_kernel, dim3(B), dim3(256), 0, stream, (const float*)ws, (long)B * K, splits,
-                       inv_nx, inv_nw, dist, bmu, K);
+    return launch_gemm(true, true, EPI_SLAB, g, bmu_splits(B, K, L), stream);
+}
+
+int vsom_bmu_cosine_finalize(const void* ws, size_t ws_bytes, const float* inv_nx, const float* inv_nw, float* dist,
+                             int64_t* bmu, int B, int K, int L, vsom_stream_t stream) {
+    VSOM_REQUIRE(inv_nx && inv_nw && bmu, VSOM_EINVAL, "bmu_cosine_finalize: null pointer");
+    VSOM_REQUIRE(B > 0 && K > 0 && L > 0, VSOM_EINVAL, "bmu_cosine_finalize: bad shape");
+    VSOM_REQUIRE(ws && ws_bytes >= vsom_bmu_cosine_workspace_bytes(B, K, L), VSOM_EWORKSPACE,
+                 "bmu_cosine_finalize: workspace too small");
+    hipLaunchKernelGGL(bmu_finalize_kernel, dim3(B), dim3(256), 0, stream, (const float*)ws, (long)B * K,
+                       bmu_splits(B, K, L), inv_nx, inv_nw, dist, bmu, K);
     VSOM_LAUNCH_CHECK("bmu_finalize_kernel");
+}
+
+int vsom_bmu_cosine_fwd(const float* X, long ldx, const float* W, const float* inv_nx, const float* inv_nw,
+                        float* dist, int64_t* bmu, int B, int K, int L, void* ws, size_t ws_bytes,
+                        vsom_stream_t stream) {
+    VSOM_REQUIRE(inv_nx && inv_nw && bmu, VSOM_EINVAL, "bmu_cosine_fwd: null pointer");
+    int rc = vsom_bmu_cosine_dots(X, ldx, W, B, K, L, ws, ws_bytes, stream);
+    if (rc) return rc;
+    return vsom_bmu_cosine_finalize(ws, ws_bytes, inv_nx, inv_nw, dist, bmu, B, K, L, stream);
 }
 
 size_t vsom_som_neigh_workspace_bytes(int B, int K) { (void)K; return B > 0 ? (size_t)B * sizeof(float) : 0; }

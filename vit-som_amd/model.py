@@ -1,0 +1,873 @@
+"""Host-side mirror of the reference's module surface for the ViT-SOM training-step hot path.
+
+Classes keep the reference's names, constructor (the YAML-schema ``config`` dict), method
+names, positional return tuples / dtypes and ``state_dict`` keys:
+
+  ViTSOM          models/vit_som.py:17-187   forward / training_step / validation_step /
+                                             configure_optimizers
+  ViTAutoencoder  models/vit.py:66-240       forward / forward_features / patchify / unpatchify
+  SOMLayer        models/som_layer.py:8-152  forward / compute_distances / update_temperature /
+                                             compute_weights / som_loss / index_to_position
+
+All arithmetic runs in libvitsom_hip.so (hand-written gfx950 kernels) through ``ops``; this file
+only owns memory (flat parameter arenas, activation buffers), ordering, schedules and the
+data-parallel exchange (one RCCL all-reduce over the gradient arena).  There is no CPU path.
+"""
+import math
+import os
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+from .arena import ParamArena
+
+try:  # the reference subclasses pl.LightningModule; do the same when Lightning is importable
+    import pytorch_lightning as pl  # type: ignore
+    _Base = pl.LightningModule
+    _HAVE_PL = True
+except Exception:  # pragma: no cover - Lightning is not in this image
+    _Base = nn.Module
+    _HAVE_PL = False
+
+
+# ------------------------------------------------------------------------------------ helpers
+def _sincos_1d(embed_dim: int, pos: np.ndarray) -> np.ndarray:
+    omega = np.arange(embed_dim // 2, dtype=np.float64) / (embed_dim / 2.0)
+    omega = 1.0 / 10000 ** omega
+    out = np.einsum("m,d->md", pos.reshape(-1).astype(np.float64), omega)
+    return np.concatenate([np.sin(out), np.cos(out)], axis=1)
+
+
+def get_2d_sincos_pos_embed(embed_dim: int, grid_size: int, cls_token: bool = False) -> np.ndarray:
+    """tools/utils.py:131-178 (float64; w-coordinate first, CLS row zeros)."""
+    gh = np.arange(grid_size, dtype=np.float32)
+    gw = np.arange(grid_size, dtype=np.float32)
+    grid = np.stack(np.meshgrid(gw, gh), axis=0).reshape(2, 1, grid_size, grid_size)
+    emb = np.concatenate([_sincos_1d(embed_dim // 2, grid[0]), _sincos_1d(embed_dim // 2, grid[1])], axis=1)
+    if cls_token:
+        emb = np.concatenate([np.zeros([1, embed_dim]), emb], axis=0)
+    return emb
+
+
+def get_layer_id_for_vit(name: str, num_layers: int) -> int:
+    """tools/utils.py:73-84."""
+    if name in ("cls_token", "pos_embed") or name.startswith("patch_embed"):
+        return 0
+    if name.startswith("blocks"):
+        return int(name.split(".")[1]) + 1
+    return num_layers
+
+
+def param_groups_lrd(model, weight_decay=0.05, no_weight_decay_list=(), layer_decay=0.75):
+    """tools/utils.py:28-71: layer/decay groups carrying an ``lr_scale`` key (inert downstream,
+    SURVEY.md 3.3 -- kept so optimizer.param_groups looks like the reference's)."""
+    groups: Dict[str, dict] = {}
+    num_layers = len(model.blocks) + 1
+    scales = [layer_decay ** (num_layers - i) for i in range(num_layers + 1)]
+    for n, p in model.named_parameters():
+        if not p.requires_grad:
+            continue
+        if p.ndim == 1 or n in no_weight_decay_list:
+            g_decay, this_decay = "no_decay", 0.0
+        else:
+            g_decay, this_decay = "decay", weight_decay
+        layer_id = get_layer_id_for_vit(n, num_layers)
+        name = "layer_%d_%s" % (layer_id, g_decay)
+        if name not in groups:
+            groups[name] = {"lr_scale": scales[layer_id], "weight_decay": this_decay, "params": []}
+        groups[name]["params"].append(p)
+    return list(groups.values())
+
+
+def _xavier_(t: torch.Tensor, fan_out: int, fan_in: int):
+    a = math.sqrt(6.0 / (fan_in + fan_out))
+    return t.uniform_(-a, a)
+
+
+class _Affine(nn.Module):
+    """Holder with ``weight`` / ``bias`` Parameters (Linear, LayerNorm, Conv2d-as-proj)."""
+
+    def __init__(self, wshape, bshape):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(wshape))
+        self.bias = nn.Parameter(torch.empty(bshape))
+
+
+class _Attention(nn.Module):          # models/vit.py:16-26
+    def __init__(self, dim, heads):
+        super().__init__()
+        self.num_heads = heads
+        self.scale = (dim // heads) ** -0.5
+        self.qkv = _Affine((3 * dim, dim), (3 * dim,))
+        self.proj = _Affine((dim, dim), (dim,))
+
+
+class Block(nn.Module):               # models/vit.py:45-57
+    def __init__(self, dim, heads, mlp_ratio):
+        super().__init__()
+        hidden = int(dim * mlp_ratio)
+        self.dim, self.heads, self.hidden = dim, heads, hidden
+        self.norm1 = _Affine((dim,), (dim,))
+        self.attn = _Attention(dim, heads)
+        self.norm2 = _Affine((dim,), (dim,))
+        self.mlp = nn.ModuleDict({"0": _Affine((hidden, dim), (hidden,)), "2": _Affine((dim, hidden), (dim,))})
+
+
+class _PatchEmbed(nn.Module):         # timm PatchEmbed attribute surface used by the reference
+    def __init__(self, img_size, patch_size, in_chans, embed_dim):
+        super().__init__()
+        self.patch_size = (patch_size, patch_size)
+        self.num_patches = (img_size // patch_size) ** 2
+        self.proj = _Affine((embed_dim, in_chans, patch_size, patch_size), (embed_dim,))
+
+
+def _trainable_order(vit: "ViTAutoencoder"):
+    """(state-dict name, parameter) in forward order: weight then bias of each layer adjacent."""
+    return [(n, p) for n, p in vit.named_parameters() if p.requires_grad]
+
+
+class _Acts:
+    """Activation / gradient buffers for one batch size (allocated once, reused every step)."""
+    pass
+
+
+# ------------------------------------------------------------------------------------ ViT autoencoder
+class ViTAutoencoder(nn.Module):
+    """MAE-style unmasked ViT autoencoder (models/vit.py:66-240); compute on the HIP kernels."""
+
+    def __init__(self, img_size=224, patch_size=16, in_chans=3, embed_dim=768, depth=12, num_heads=12,
+                 decoder_embed_dim=512, decoder_depth=8, decoder_num_heads=16, mlp_ratio=4.0, norm_layer=None,
+                 norm_pix_loss=False, eps: float = 1e-6):
+        super().__init__()
+        self.img_size, self.in_chans, self.eps = img_size, in_chans, eps
+        self.embed_dim, self.decoder_embed_dim = embed_dim, decoder_embed_dim
+        self.num_heads, self.decoder_num_heads = num_heads, decoder_num_heads
+        self.patch_embed = _PatchEmbed(img_size, patch_size, in_chans, embed_dim)
+        n = self.patch_embed.num_patches
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
+        self.pos_embed = nn.Parameter(torch.zeros(1, n + 1, embed_dim), requires_grad=False)
+        self.blocks = nn.ModuleList([Block(embed_dim, num_heads, mlp_ratio) for _ in range(depth)])
+        self.norm = _Affine((embed_dim,), (embed_dim,))
+        self.decoder_embed = _Affine((decoder_embed_dim, embed_dim), (decoder_embed_dim,))
+        self.decoder_pos_embed = nn.Parameter(torch.zeros(1, n + 1, decoder_embed_dim), requires_grad=False)
+        self.decoder_blocks = nn.ModuleList([Block(decoder_embed_dim, decoder_num_heads, mlp_ratio)
+                                             for _ in range(decoder_depth)])
+        self.decoder_norm = _Affine((decoder_embed_dim,), (decoder_embed_dim,))
+        self.decoder_pred = _Affine((patch_size ** 2 * in_chans, decoder_embed_dim), (patch_size ** 2 * in_chans,))
+        self.initialize_weights()
+        self._acts: Dict[int, _Acts] = {}
+
+    # -- init: same distributions as vit.py:100-125 ------------------------------------------
+    def initialize_weights(self):
+        g = int(self.patch_embed.num_patches ** 0.5)
+        with torch.no_grad():
+            self.pos_embed.copy_(torch.from_numpy(get_2d_sincos_pos_embed(self.embed_dim, g, True)).float().unsqueeze(0))
+            self.decoder_pos_embed.copy_(
+                torch.from_numpy(get_2d_sincos_pos_embed(self.decoder_embed_dim, g, True)).float().unsqueeze(0))
+            w = self.patch_embed.proj.weight
+            _xavier_(w, w.shape[0], w[0].numel())
+            bound = 1.0 / math.sqrt(w[0].numel())                    # Conv2d default bias init (untouched by _init_weights)
+            self.patch_embed.proj.bias.uniform_(-bound, bound)
+            self.cls_token.normal_(std=0.02)
+            for name, m in self.named_modules():
+                if not isinstance(m, _Affine) or m is self.patch_embed.proj:
+                    continue
+                if m.weight.ndim == 2:                                # nn.Linear: xavier_uniform / zero bias
+                    _xavier_(m.weight, m.weight.shape[0], m.weight.shape[1])
+                    m.bias.zero_()
+                else:                                                 # nn.LayerNorm
+                    m.weight.fill_(1.0)
+                    m.bias.zero_()
+
+    # -- pure index shuffles kept for API parity (torch view ops: no arithmetic) -------------
+    def patchify(self, imgs):
+        p = self.patch_embed.patch_size[0]
+        assert imgs.shape[2] == imgs.shape[3] and imgs.shape[2] % p == 0
+        h = w = imgs.shape[2] // p
+        c = imgs.shape[1]
+        x = imgs.reshape(imgs.shape[0], c, h, p, w, p)
+        return torch.einsum("nchpwq->nhwpqc", x).reshape(imgs.shape[0], h * w, p ** 2 * c)
+
+    def unpatchify(self, x):
+        p = self.patch_embed.patch_size[0]
+        h = w = int(x.shape[1] ** 0.5)
+        assert h * w == x.shape[1]
+        c = x.shape[2] // (p * p)
+        x = x.reshape(x.shape[0], h, w, p, p, c)
+        return torch.einsum("nhwpqc->nchpwq", x).reshape(x.shape[0], c, h * p, w * p)
+
+    # -- buffers ------------------------------------------------------------------------------
+    def _buffers_for(self, B: int, device) -> _Acts:
+        a = self._acts.get(B)
+        if a is not None and a.device == device:
+            return a
+        E, DE = self.embed_dim, self.decoder_embed_dim
+        n = self.patch_embed.num_patches
+        N, T = n + 1, B * (n + 1)
+        p = self.patch_embed.patch_size[0]
+        pd = p * p * self.in_chans
+        f = lambda *s: torch.empty(*s, dtype=torch.float32, device=device)   # noqa: E731
+        a = _Acts()
+        a.device, a.B, a.N, a.T = device, B, N, T
+        a.xp = f(B * n, pd)
+        a.tok0 = f(T, E)
+
+        def layer(dim, heads, hidden):
+            L = _Acts()
+            L.a1, L.mean1, L.rstd1 = f(T, dim), f(T), f(T)
+            L.qkv, L.ao, L.lse = f(T, 3 * dim), f(T, dim), f(B, heads, N)
+            L.x1, L.a2, L.mean2, L.rstd2 = f(T, dim), f(T, dim), f(T), f(T)
+            L.hpre, L.hact, L.x2 = f(T, hidden), f(T, hidden), f(T, dim)
+            return L
+        a.enc = [layer(E, self.num_heads, b.hidden) for b in self.blocks]
+        a.xe, a.mean_e, a.rstd_e = f(T, E), f(T), f(T)
+        a.dec0 = f(T, DE)
+        a.dec = [layer(DE, self.decoder_num_heads, b.hidden) for b in self.decoder_blocks]
+        a.dn, a.mean_d, a.rstd_d = f(T, DE), f(T), f(T)
+        a.pred = f(T, pd)
+        # backward temporaries (shared by all layers; sized for the wider of encoder / decoder)
+        W = max(E, DE)
+        Hd = max([b.hidden for b in self.blocks] + [b.hidden for b in self.decoder_blocks])
+        a.g = [f(T * W) for _ in range(3)]
+        a.dh, a.dqkv, a.da = f(T * Hd), f(T * 3 * W), f(T * W)
+        a.delta = f(B * max(self.num_heads, self.decoder_num_heads) * N)
+        a.dpred = f(T, pd)
+        a.d_xe = f(T, E)
+        self._acts = {B: a}
+        return a
+
+    # -- forward ------------------------------------------------------------------------------
+    def _block_fwd(self, blk: Block, L: _Acts, x_in: torch.Tensor, B: int, N: int):
+        T = B * N
+        ops.layernorm_fwd(x_in, blk.norm1.weight, blk.norm1.bias, L.a1, L.mean1, L.rstd1, self.eps)
+        ops.linear_fwd(L.a1, blk.attn.qkv.weight, blk.attn.qkv.bias, L.qkv)
+        ops.attention_fwd(L.qkv, L.ao, L.lse, B, N, blk.heads, blk.dim // blk.heads)
+        ops.linear_residual_fwd(L.ao, blk.attn.proj.weight, blk.attn.proj.bias, x_in, T, L.x1)
+        ops.layernorm_fwd(L.x1, blk.norm2.weight, blk.norm2.bias, L.a2, L.mean2, L.rstd2, self.eps)
+        ops.linear_gelu_fwd(L.a2, blk.mlp["0"].weight, blk.mlp["0"].bias, L.hpre, L.hact)
+        ops.linear_residual_fwd(L.hact, blk.mlp["2"].weight, blk.mlp["2"].bias, L.x1, T, L.x2)
+        return L.x2
+
+    def _encode(self, x: torch.Tensor, a: _Acts):
+        E = self.embed_dim
+        p = self.patch_embed.patch_size[0]
+        ops.patch_embed_fwd(x, self.patch_embed.proj.weight.view(E, -1), self.patch_embed.proj.bias, self.pos_embed[0],
+                            self.cls_token.view(E), a.tok0, a.xp, p)
+        cur = a.tok0
+        for blk, L in zip(self.blocks, a.enc):
+            cur = self._block_fwd(blk, L, cur, a.B, a.N)
+        ops.layernorm_fwd(cur, self.norm.weight, self.norm.bias, a.xe, a.mean_e, a.rstd_e, self.eps)
+        return a.xe
+
+    def _decode(self, a: _Acts):
+        ops.linear_residual_fwd(a.xe, self.decoder_embed.weight, self.decoder_embed.bias, self.decoder_pos_embed[0],
+                                a.N, a.dec0)
+        cur = a.dec0
+        for blk, L in zip(self.decoder_blocks, a.dec):
+            cur = self._block_fwd(blk, L, cur, a.B, a.N)
+        ops.layernorm_fwd(cur, self.decoder_norm.weight, self.decoder_norm.bias, a.dn, a.mean_d, a.rstd_d, self.eps)
+        ops.linear_fwd(a.dn, self.decoder_pred.weight, self.decoder_pred.bias, a.pred)
+        return a.pred
+
+    def _check_input(self, x):
+        if x.dim() != 4 or x.shape[1] != self.in_chans or x.shape[2] != self.img_size or x.shape[3] != self.img_size:
+            raise ValueError(f"expected input [B,{self.in_chans},{self.img_size},{self.img_size}], got {tuple(x.shape)}")
+        return x.contiguous().float()
+
+    @torch.no_grad()
+    def forward_features(self, x, return_attns=False):
+        """vit.py:155-179 -> (cls_token_out, None)."""
+        if return_attns:
+            raise NotImplementedError("attention maps are never materialised by the fused kernels")
+        x = self._check_input(x)
+        a = self._buffers_for(x.shape[0], x.device)
+        xe = self._encode(x, a).view(a.B, a.N, self.embed_dim)
+        return xe[:, 0].clone(), None
+
+    @torch.no_grad()
+    def forward(self, x, return_attns=False):
+        """vit.py:202-240 -> (cls_token_out [B,E], patch_tokens_out [B,n,E], recon_img [B,C,S,S])."""
+        if return_attns:
+            raise NotImplementedError("attention maps are never materialised by the fused kernels")
+        x = self._check_input(x)
+        a = self._buffers_for(x.shape[0], x.device)
+        xe = self._encode(x, a).view(a.B, a.N, self.embed_dim)
+        self._decode(a)
+        recon = torch.empty_like(x)
+        scratch1 = torch.empty(1, dtype=torch.float32, device=x.device)
+        ops.l1_unpatchify(a.pred, x, scratch1, recon=recon, p=self.patch_embed.patch_size[0])
+        return xe[:, 0].clone(), xe[:, 1:].clone(), recon
+
+    # -- backward -----------------------------------------------------------------------------
+    def _block_bwd(self, blk: Block, L: _Acts, x_in, gout, a: _Acts, G, prefix: str, bufs):
+        """gout: gradient w.r.t. the block output [T,dim]; returns gradient w.r.t. x_in (in bufs)."""
+        T, dim, hid = a.T, blk.dim, blk.hidden
+        g1, g0 = bufs
+        dh = a.dh[:T * hid].view(T, hid)
+        da = a.da[:T * dim].view(T, dim)
+        dqkv = a.dqkv[:T * 3 * dim].view(T, 3 * dim)
+        ops.linear_bwd_weight(gout, L.hact, G(f"{prefix}.mlp.2.weight"), G(f"{prefix}.mlp.2.bias"))
+        ops.linear_bwd_input(gout, blk.mlp["2"].weight, dh, gelu_pre=L.hpre)
+        ops.linear_bwd_weight(dh, L.a2, G(f"{prefix}.mlp.0.weight"), G(f"{prefix}.mlp.0.bias"))
+        ops.linear_bwd_input(dh, blk.mlp["0"].weight, da)
+        ops.layernorm_bwd(da, L.x1, L.mean2, L.rstd2, blk.norm2.weight, gout, g1, G(f"{prefix}.norm2.weight"),
+                          G(f"{prefix}.norm2.bias"))
+        ops.linear_bwd_weight(g1, L.ao, G(f"{prefix}.attn.proj.weight"), G(f"{prefix}.attn.proj.bias"))
+        ops.linear_bwd_input(g1, blk.attn.proj.weight, da)
+        ops.attention_bwd(L.qkv, L.ao, da, L.lse, dqkv, a.delta, a.B, a.N, blk.heads, dim // blk.heads)
+        ops.linear_bwd_weight(dqkv, L.a1, G(f"{prefix}.attn.qkv.weight"), G(f"{prefix}.attn.qkv.bias"))
+        ops.linear_bwd_input(dqkv, blk.attn.qkv.weight, da)
+        ops.layernorm_bwd(da, x_in, L.mean1, L.rstd1, blk.norm1.weight, g1, g0, G(f"{prefix}.norm1.weight"),
+                          G(f"{prefix}.norm1.bias"))
+        return g0
+
+    def _views(self, a: _Acts, dim: int):
+        return [b[:a.T * dim].view(a.T, dim) for b in a.g]
+
+    def _decoder_bwd(self, a: _Acts, G):
+        """a.dpred holds dL/dpred; writes decoder grads and dL/d(xe) into a.d_xe (overwrite)."""
+        DE = self.decoder_embed_dim
+        gA, gB, gC = self._views(a, DE)
+        ops.linear_bwd_weight(a.dpred, a.dn, G("decoder_pred.weight"), G("decoder_pred.bias"))
+        dn_grad = a.da[:a.T * DE].view(a.T, DE)
+        ops.linear_bwd_input(a.dpred, self.decoder_pred.weight, dn_grad)
+        x_last = a.dec[-1].x2 if a.dec else a.dec0
+        ops.layernorm_bwd(dn_grad, x_last, a.mean_d, a.rstd_d, self.decoder_norm.weight, None, gA,
+                          G("decoder_norm.weight"), G("decoder_norm.bias"))
+        gout, free = gA, [gB, gC]
+        for i in reversed(range(len(self.decoder_blocks))):
+            x_in = a.dec[i - 1].x2 if i > 0 else a.dec0
+            g0 = self._block_bwd(self.decoder_blocks[i], a.dec[i], x_in, gout, a, G, f"decoder_blocks.{i}", free)
+            free = [b for b in (gA, gB, gC) if b is not g0]
+            gout = g0
+        ops.linear_bwd_weight(gout, a.xe, G("decoder_embed.weight"), G("decoder_embed.bias"))
+        ops.linear_bwd_input(gout, self.decoder_embed.weight, a.d_xe)
+
+    def _encoder_bwd(self, a: _Acts, G):
+        """a.d_xe holds dL/d(xe); writes every encoder gradient."""
+        E = self.embed_dim
+        gA, gB, gC = self._views(a, E)
+        x_last = a.enc[-1].x2 if a.enc else a.tok0
+        ops.layernorm_bwd(a.d_xe, x_last, a.mean_e, a.rstd_e, self.norm.weight, None, gA, G("norm.weight"), G("norm.bias"))
+        gout, free = gA, [gB, gC]
+        for i in reversed(range(len(self.blocks))):
+            x_in = a.enc[i - 1].x2 if i > 0 else a.tok0
+            g0 = self._block_bwd(self.blocks[i], a.enc[i], x_in, gout, a, G, f"blocks.{i}", free)
+            free = [b for b in (gA, gB, gC) if b is not g0]
+            gout = g0
+        p = self.patch_embed.patch_size[0]
+        ops.patch_embed_bwd(gout, a.xp, G("patch_embed.proj.weight").view(E, -1), G("patch_embed.proj.bias"),
+                            G("cls_token").view(E), a.B, self.in_chans, self.img_size, p, E)
+
+
+# ------------------------------------------------------------------------------------ SOM layer
+class SOMLayer(_Base):
+    """models/som_layer.py:8-152 on the HIP kernels (cosine distance; square / hexa topology)."""
+
+    def __init__(self, config):
+        super().__init__()
+        hp = config["hyperparameters"]
+        self.model_arch = hp["model_arch"]
+        som_hp, data_hp = hp["som"], config["data"]
+        vit_hp = hp["vit"] if self.model_arch == "vit_som" else None
+        self.total_epochs, self.batch_size = hp["total_epochs"], hp["batch_size"]
+        self.map_size = som_hp["map_size"]
+        self.Tmax, self.Tmin = som_hp["Tmax"], som_hp["Tmin"]
+        self.topology, self.distance_fcn = som_hp["topology"], som_hp["distance_fcn"]
+        self.n_prototypes = int(np.prod(self.map_size))
+        if self.model_arch != "vit_som":
+            raise NotImplementedError("only model_arch == 'vit_som' is on the accelerated path")
+        if self.distance_fcn != "cosine":
+            raise NotImplementedError(
+                f"distance_fcn={self.distance_fcn!r}: only 'cosine' (every shipped vit_som config) has a HIP kernel yet")
+        self.use_reduced = som_hp["use_reduced"]
+        latent_dim = vit_hp["emb_dim"]
+        if not self.use_reduced:
+            latent_dim *= (data_hp["input_size"] // vit_hp["patch_size"]) ** 2
+        self.latent_dim = latent_dim
+        self.current_temperature = self.Tmax
+        self.prototypes = nn.Parameter(torch.nn.functional.normalize(torch.rand(self.n_prototypes, latent_dim), p=2, dim=1))
+        self.create_grid_positions()
+        self._world_size = 1
+        self._n_train: Optional[int] = None
+        self._bufs: Dict[int, _Acts] = {}
+
+    def create_grid_positions(self):                                   # som_layer.py:60-81
+        if self.topology == "square":
+            gy, gx = torch.meshgrid(torch.arange(self.map_size[0]), torch.arange(self.map_size[1]), indexing="ij")
+            positions = torch.stack([gy, gx], dim=-1).view(-1, 2).float()
+        elif self.topology == "hexa":
+            rows, cols = self.map_size
+            positions = torch.zeros(self.n_prototypes, 2)
+            for i in range(self.n_prototypes):
+                row, col = i // cols, i % cols
+                positions[i, 0] = col + (0.5 if row % 2 == 1 else 0.0)
+                positions[i, 1] = row * np.sqrt(3) / 2
+        else:
+            raise ValueError(f"Unsupported topology: {self.topology}")
+        self.register_buffer("grid_positions", positions)
+
+    def _buffers_for(self, B: int, device) -> _Acts:
+        s = self._bufs.get(B)
+        if s is not None and s.device == device:
+            return s
+        K = self.n_prototypes
+        f = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=device)   # noqa: E731
+        s = _Acts()
+        s.device = device
+        s.inx, s.inw = f(B), f(K)
+        s.dist, s.bmu = f(B, K), torch.empty(B, dtype=torch.int64, device=device)
+        s.coef, s.row_dot, s.col_dot = f(B, K), f(B), f(K)
+        s.loss_sum = f(1)
+        self._bufs = {B: s}
+        return s
+
+    # reference API -----------------------------------------------------------------------
+    @torch.no_grad()
+    def compute_distances(self, x):                                    # som_layer.py:111-125
+        if x.dim() > 2:
+            x = x.flatten(start_dim=1)
+        s = self._buffers_for(x.shape[0], x.device)
+        self._distances_into(x, s)
+        return s.dist.clone()
+
+    def _distances_into(self, x2d, s: _Acts):
+        ops.row_inv_norm(x2d, s.inx)
+        ops.row_inv_norm(self.prototypes, s.inw)
+        ops.bmu_cosine_fwd(x2d, self.prototypes, s.inx, s.inw, s.dist, s.bmu)
+
+    @torch.no_grad()
+    def forward(self, x):                                              # som_layer.py:83-89
+        if x.dim() > 2:
+            x = x.flatten(start_dim=1)
+        x = x.float()
+        if x.stride(-1) != 1:
+            x = x.contiguous()
+        s = self._buffers_for(x.shape[0], x.device)
+        self._distances_into(x, s)
+        return s.dist.clone(), s.bmu.clone()
+
+    def total_iterations(self) -> float:
+        n = self._n_train
+        if n is None:
+            tr = getattr(self, "_trainer_ref", None)
+            if tr is None:
+                raise RuntimeError("SOMLayer: call ViTSOM.set_schedule(n_train, estimated_stepping_batches) "
+                                   "or attach a trainer before training_step")
+            n = len(tr.train_dataloader.dataset)
+        # single-process semantics on the GLOBAL batch (the reference divides by the per-rank
+        # batch size only, som_layer.py:131 -- SURVEY.md section 5, defect (b))
+        return (n / (self.batch_size * self._world_size)) * self.total_epochs
+
+    def update_temperature(self, iteration):                           # som_layer.py:127-132
+        it = float(iteration)
+        self.current_temperature = self.Tmax * (self.Tmin / self.Tmax) ** (it / (self.total_iterations() - 1))
+
+    def index_to_position(self, indices):                              # som_layer.py:134-135
+        return torch.stack((indices // self.map_size[1], indices % self.map_size[1]), dim=1).float()
+
+    @torch.no_grad()
+    def compute_weights(self, bmu_indices):                            # som_layer.py:144-152
+        B, K = bmu_indices.shape[0], self.n_prototypes
+        dev = bmu_indices.device
+        h = torch.empty(B, K, dtype=torch.float32, device=dev)
+        zero_d = torch.zeros(B, K, dtype=torch.float32, device=dev)
+        tmp = torch.empty(1, dtype=torch.float32, device=dev)
+        ops.som_neigh_loss(zero_d, bmu_indices.contiguous(), self.grid_positions, float(self.current_temperature), tmp, h=h)
+        return h
+
+    @torch.no_grad()
+    def som_loss(self, weights, distances):                            # som_layer.py:137-142
+        """mean(h * d).  Given the weights of compute_weights this is recomputed from (bmu, T) in
+        one fused pass; arbitrary `weights` tensors are not supported on the accelerated path."""
+        B, K = distances.shape
+        bmu = torch.argmax(weights, dim=1)        # h_ik is maximal (== 1) exactly at k = bmu(i)  [index plumbing]
+        tmp = torch.empty(1, dtype=torch.float32, device=distances.device)
+        ops.som_neigh_loss(distances.contiguous(), bmu, self.grid_positions, float(self.current_temperature), tmp)
+        return tmp[0] / (B * K)
+
+
+# ------------------------------------------------------------------------------------ optimiser
+class FusedAdamW(torch.optim.Optimizer):
+    """torch.optim.AdamW / Adam semantics (vit_som.py:146-157) as ONE kernel over the flat arena.
+
+    ``param_groups`` mirror the reference's (layer/decay groups with the inert ``lr_scale`` key
+    plus the prototypes/cls_head group with AdamW's default weight_decay=0.01).  All groups
+    share one lr (the reference's single-lambda LambdaLR scales them equally).  ``step()``
+    first sums the gradient arena across ranks (RCCL all-reduce) when world_size > 1."""
+
+    def __init__(self, model: "ViTSOM", param_groups, lr, betas, adamw=True, eps=1e-8):
+        defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=0.01 if adamw else 0.0)
+        super().__init__(param_groups, defaults)
+        self._model = model
+        self._adamw = adamw
+        self._step = 0
+        # per-chunk weight decay follows the groups
+        name_of = {id(p): n for n, p in model._named_trainable()}
+        for g in self.param_groups:
+            for p in g["params"]:
+                model.arena.set_weight_decay(name_of[id(p)], float(g["weight_decay"]))
+        if model.classification:
+            # the reference leaves the decoder without gradients in classification mode, so
+            # torch's AdamW never touches it (no decay either) -- SURVEY.md section 5 defect (a)
+            for n in model._decoder_param_names():
+                model.arena.set_weight_decay(n, 0.0)
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        m = self._model
+        m.allreduce_gradients()
+        self._step += 1
+        g0 = self.param_groups[0]
+        lrs = {float(g["lr"]) for g in self.param_groups}
+        if len(lrs) != 1:
+            raise RuntimeError("FusedAdamW: per-group learning rates differ; the arena kernel uses one lr")
+        b1, b2 = g0["betas"]
+        ops.adamw_step(m.arena.params, m.arena.grads, m.arena.exp_avg, m.arena.exp_avg_sq, m.arena.wd_chunk,
+                       float(g0["lr"]), b1, b2, g0["eps"], self._step, grad_scale=1.0 / m.world_size, adamw=self._adamw)
+        return loss
+
+    def zero_grad(self, set_to_none: bool = True):
+        # gradients are fully overwritten by every backward pass; nothing to clear
+        return None
+
+    def state_dict(self):
+        sd = super().state_dict()
+        sd["fused"] = {"step": self._step, "exp_avg": self._model.arena.exp_avg.clone(),
+                       "exp_avg_sq": self._model.arena.exp_avg_sq.clone()}
+        return sd
+
+    def load_state_dict(self, sd):
+        fused = sd.pop("fused", None)
+        super().load_state_dict(sd)
+        if fused is not None:
+            self._step = int(fused["step"])
+            self._model.arena.exp_avg.copy_(fused["exp_avg"])
+            self._model.arena.exp_avg_sq.copy_(fused["exp_avg_sq"])
+
+
+# ------------------------------------------------------------------------------------ autograd bridge
+class _StepLoss(torch.autograd.Function):
+    """Makes the fused step look like one differentiable scalar to torch / Lightning:
+    forward = all HIP forward kernels + losses, backward = all HIP backward kernels writing the
+    gradient arena (then scaled by the incoming scalar gradient)."""
+
+    @staticmethod
+    def forward(ctx, anchor, model, x, y, gamma_t, T):
+        ctx.model = model
+        return model._forward_losses(x, y, gamma_t, T, want_grad=True).clone()
+
+    @staticmethod
+    def backward(ctx, gout):
+        m = ctx.model
+        m._backward()
+        m.arena.grads.mul_(gout)           # 1.0 under a plain loss.backward()
+        m._expose_grads()
+        return None, None, None, None, None, None
+
+
+# ------------------------------------------------------------------------------------ ViT-SOM
+class ViTSOM(_Base):
+    """Vision Transformer Self-Organizing Map (models/vit_som.py:17-187), MI355X-native."""
+
+    def __init__(self, config, device=None):
+        super().__init__()
+        # NOTE: unlike vit_som.py:23 this does NOT lower torch's global float32 matmul precision:
+        # every contraction here is exact fp32 on MFMA.
+        self.config = config
+        if _HAVE_PL:
+            self.save_hyperparameters(config)
+        hp, data_hp = config["hyperparameters"], config["data"]
+        vit_hp, opt_hp, som_hp = hp["vit"], hp["optimizer"], hp["som"]
+        self.gamma = hp["gamma"]
+        self.use_reduced = som_hp["use_reduced"]
+        self.classification = data_hp["num_classes"] > 0
+        self.vit = ViTAutoencoder(
+            img_size=data_hp["input_size"], patch_size=vit_hp["patch_size"], in_chans=data_hp["num_channels"],
+            embed_dim=vit_hp["emb_dim"], depth=vit_hp["depth"], num_heads=vit_hp["heads"],
+            decoder_embed_dim=vit_hp["dec_emb_dim"], decoder_depth=vit_hp["dec_depth"],
+            decoder_num_heads=vit_hp["heads"], mlp_ratio=vit_hp["mlp_ratio"], eps=1e-6)
+        self.som_layer = SOMLayer(config)
+        if self.classification:
+            self.cls_head = _Affine((data_hp["num_classes"], vit_hp["emb_dim"]), (data_hp["num_classes"],))
+            with torch.no_grad():
+                self.cls_head.weight.normal_(std=0.02)
+                bound = 1.0 / math.sqrt(vit_hp["emb_dim"])
+                self.cls_head.bias.uniform_(-bound, bound)
+        self.smoothing = float(opt_hp["smoothing"])
+        self.register_buffer("iteration", torch.tensor(0))
+        self._it = 0
+        self._n_train: Optional[int] = None
+        self._est_steps: Optional[int] = None
+        self.world_size, self.rank = 1, 0
+        self._last: Dict[str, torch.Tensor] = {}
+        self.arena: Optional[ParamArena] = None
+        if device is None:
+            device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+        self._pack(torch.device(device))
+
+    # -- arenas -------------------------------------------------------------------------------
+    def _named_trainable(self):
+        return [(n, p) for n, p in self.named_parameters() if p.requires_grad]
+
+    def _decoder_param_names(self):
+        return [n for n, _ in self._named_trainable() if n.startswith("vit.decoder_")]
+
+    def _pack(self, device):
+        """(Re)build the flat arenas on `device` and re-point every Parameter at its view."""
+        old_wd = self.arena.wd_by_name if self.arena is not None else {}
+        named = self._named_trainable()
+        specs = []
+        for n, p in named:
+            if n in old_wd:
+                wd = old_wd[n]
+            elif n.startswith("vit."):
+                wd = 0.0 if p.ndim == 1 else 0.05
+            else:
+                wd = 0.01
+            specs.append((n, tuple(p.shape), wd))
+        arena = ParamArena(specs, device)
+        with torch.no_grad():
+            for n, p in named:
+                v = arena.p(n)
+                v.copy_(p.detach().to(device))
+                p.data = v
+            for n, b in list(self.named_buffers()) + [(n, p) for n, p in self.named_parameters() if not p.requires_grad]:
+                if b.device != device:
+                    b.data = b.data.to(device)
+        if self.arena is not None and self.arena.device == device:
+            arena.exp_avg.copy_(self.arena.exp_avg)
+            arena.exp_avg_sq.copy_(self.arena.exp_avg_sq)
+        self.arena = arena
+        self._anchor = None
+        self._grad_views = {n: arena.g(n) for n, _ in named}
+
+    def _apply(self, fn, *args, **kwargs):
+        super()._apply(fn, *args, **kwargs)
+        dev = next(self.parameters()).device
+        aliased = all(p.data_ptr() == self.arena.p(n).data_ptr() for n, p in self._named_trainable())
+        if not aliased or dev != self.arena.device:
+            self._pack(dev)
+        return self
+
+    def _G(self, prefix: str):
+        return lambda name: self._grad_views[prefix + name]
+
+    def _expose_grads(self):
+        for n, p in self._named_trainable():
+            p.grad = self._grad_views[n]
+
+    # -- schedules ----------------------------------------------------------------------------
+    def set_schedule(self, n_train: int, estimated_stepping_batches: int):
+        """Trainer-less replacement for len(trainer.train_dataloader.dataset) and
+        trainer.estimated_stepping_batches (som_layer.py:131, vit_som.py:89)."""
+        self._n_train, self._est_steps = int(n_train), int(estimated_stepping_batches)
+        self.som_layer._n_train = int(n_train)
+
+    def set_distributed(self, world_size: int, rank: int = 0):
+        self.world_size, self.rank = int(world_size), int(rank)
+        self.som_layer._world_size = int(world_size)
+
+    def _estimated_steps(self) -> int:
+        if self._est_steps is not None:
+            return self._est_steps
+        tr = getattr(self, "_trainer", None) if not _HAVE_PL else getattr(self, "trainer", None)
+        if tr is None:
+            raise RuntimeError("ViTSOM: call set_schedule(n_train, estimated_stepping_batches) or attach a trainer")
+        self.som_layer._trainer_ref = tr
+        return int(tr.estimated_stepping_batches)
+
+    def _gamma_t(self) -> float:                                        # vit_som.py:89-90 (host int, no .item() sync)
+        ramp_up_end_step = self._estimated_steps() // 2
+        return self.config["hyperparameters"]["gamma"] * min(1.0, self._it / ramp_up_end_step)
+
+    def _log(self, *a, **k):
+        if _HAVE_PL and getattr(self, "_trainer", None) is not None:
+            try:
+                self.log_dict(*a, **k) if isinstance(a[0], dict) else self.log(*a, **k)
+            except Exception:
+                pass
+
+    # -- fused forward + losses ---------------------------------------------------------------
+    def _som_input(self, a: _Acts):
+        E, N, B = self.vit.embed_dim, a.N, a.B
+        if self.use_reduced:
+            return torch.as_strided(a.xe, (B, E), (N * E, 1), a.xe.storage_offset())
+        return torch.as_strided(a.xe, (B, (N - 1) * E), (N * E, 1), a.xe.storage_offset() + E)
+
+    def _cls_view(self, buf: torch.Tensor, a: _Acts):
+        E = self.vit.embed_dim
+        return torch.as_strided(buf, (a.B, E), (a.N * E, 1), buf.storage_offset())
+
+    @torch.no_grad()
+    def _run_forward(self, x, need_decoder: bool):
+        x = self.vit._check_input(x)
+        if not x.is_cuda:
+            raise ValueError("ViTSOM: input must live on the MI355X (there is no CPU path)")
+        a = self.vit._buffers_for(x.shape[0], x.device)
+        self.vit._encode(x, a)
+        if need_decoder:
+            self.vit._decode(a)
+        s = self.som_layer._buffers_for(a.B, x.device)
+        self.som_layer._distances_into(self._som_input(a), s)
+        if self.classification:
+            if not hasattr(a, "logits"):
+                a.logits = torch.empty(a.B, self.cls_head.weight.shape[0], dtype=torch.float32, device=x.device)
+                a.dlogits = torch.empty_like(a.logits)
+            ops.linear_fwd(self._cls_view(a.xe, a), self.cls_head.weight, self.cls_head.bias, a.logits)
+        return x, a, s
+
+    @torch.no_grad()
+    def forward(self, x):
+        """vit_som.py:67-78 -> (cls_token, recon_img, logits | None, distances, bmu_indices[int64])."""
+        x, a, s = self._run_forward(x, need_decoder=True)
+        recon = torch.empty_like(x)
+        tmp = torch.empty(1, dtype=torch.float32, device=x.device)
+        ops.l1_unpatchify(a.pred, x, tmp, recon=recon, p=self.vit.patch_embed.patch_size[0])
+        cls = self._cls_view(a.xe, a).clone()
+        logits = a.logits.clone() if self.classification else None
+        return cls, recon, logits, s.dist.clone(), s.bmu.clone()
+
+    @torch.no_grad()
+    def _forward_losses(self, x, y, gamma_t: float, T: float, want_grad: bool):
+        """All forward kernels + both losses (+ loss-side gradients when want_grad).  Returns the
+        total loss as a 0-dim device tensor; parts land in self._last."""
+        x, a, s = self._run_forward(x, need_decoder=not self.classification)
+        B, K = a.B, self.som_layer.n_prototypes
+        self._ctx = (x, a, s)
+        dev = x.device
+        if not hasattr(a, "main_sum"):
+            a.main_sum = torch.empty(1, dtype=torch.float32, device=dev)
+        c = gamma_t / (B * K)
+        if want_grad:
+            ops.som_neigh_loss(s.dist, s.bmu, self.som_layer.grid_positions, T, s.loss_sum, inv_nx=s.inx, inv_nw=s.inw,
+                               grad_scale=c, coef=s.coef, row_dot=s.row_dot, col_dot=s.col_dot)
+        else:
+            ops.som_neigh_loss(s.dist, s.bmu, self.som_layer.grid_positions, T, s.loss_sum)
+        if self.classification:
+            yv = y.view(-1)
+            if yv.dtype != torch.int64:
+                yv = yv.long()
+            ops.cross_entropy_ls(a.logits, yv.contiguous(), self.smoothing, a.main_sum,
+                                 dlogits=a.dlogits if want_grad else None, grad_scale=1.0 / B)
+            main = a.main_sum[0] / B
+        else:
+            ops.l1_unpatchify(a.pred, x, a.main_sum, dpred=a.dpred if want_grad else None, grad_scale=1.0 / x.numel(),
+                              p=self.vit.patch_embed.patch_size[0])
+            main = a.main_sum[0] / x.numel()
+        som = s.loss_sum[0] / (B * K)
+        total = main + gamma_t * som
+        self._last = {"main": main, "som": som, "total": total, "gamma_t": gamma_t, "T": T}
+        return total
+
+    @torch.no_grad()
+    def _backward(self):
+        """All backward kernels; overwrites the whole gradient arena (no accumulation)."""
+        x, a, s = self._ctx
+        Gv = self._G("vit.")
+        if self.classification:
+            ops.fill(a.d_xe, 0.0)
+            # decoder is unused by the classification loss: its gradients are exactly zero
+            for n in self._decoder_param_names():
+                ops.fill(self._grad_views[n], 0.0)
+            ops.linear_bwd_weight(a.dlogits, self._cls_view(a.xe, a), self._grad_views["cls_head.weight"],
+                                  self._grad_views["cls_head.bias"])
+            ops.linear_bwd_input(a.dlogits, self.cls_head.weight, self._cls_view(a.d_xe, a), accumulate=True)
+        else:
+            self.vit._decoder_bwd(a, Gv)
+        X = self._som_input(a)
+        E, N = self.vit.embed_dim, a.N
+        if self.use_reduced:
+            gX = torch.as_strided(a.d_xe, (a.B, E), (N * E, 1), a.d_xe.storage_offset())
+        else:
+            gX = torch.as_strided(a.d_xe, (a.B, (N - 1) * E), (N * E, 1), a.d_xe.storage_offset() + E)
+        ops.som_bwd(X, self.som_layer.prototypes, s.coef, s.row_dot, s.col_dot, self._grad_views["som_layer.prototypes"],
+                    gX, accumulate_gx=True)
+        self.vit._encoder_bwd(a, Gv)
+
+    # -- data-parallel exchange ----------------------------------------------------------------
+    def allreduce_gradients(self):
+        """Sum the whole gradient arena (ViT grads + prototype accumulators) across ranks with one
+        RCCL all-reduce over xGMI; AdamW divides by world_size."""
+        if self.world_size > 1:
+            import torch.distributed as dist
+            dist.all_reduce(self.arena.grads, op=dist.ReduceOp.SUM)
+
+    # -- reference API ---------------------------------------------------------------------------
+    def _schedules_for_step(self):
+        self.som_layer.update_temperature(self._it)                     # vit_som.py:84 (iteration BEFORE increment)
+        return self._gamma_t(), float(self.som_layer.current_temperature)
+
+    def training_step(self, batch, batch_idx):
+        """vit_som.py:80-105.  Returns a scalar tensor; ``.backward()`` runs the HIP backward."""
+        x, y = batch
+        self._estimated_steps()
+        gamma_t, T = self._schedules_for_step()
+        if self._anchor is None:
+            self._anchor = torch.zeros((), device=self.arena.device, requires_grad=True)
+        total = _StepLoss.apply(self._anchor, self, x, y, gamma_t, T)
+        self._advance()
+        return total
+
+    def train_step_fused(self, x, y):
+        """Same step without the autograd bridge: forward + losses + backward into the gradient
+        arena (the caller then runs optimizer.step()).  Returns the loss tensor."""
+        self._estimated_steps()
+        gamma_t, T = self._schedules_for_step()
+        total = self._forward_losses(x, y, gamma_t, T, want_grad=True)
+        self._backward()
+        self._advance()
+        return total
+
+    def _advance(self):
+        self._it += 1
+        self.iteration += 1                                             # vit_som.py:104 (device buffer, no sync)
+
+    def validation_step(self, batch, batch_idx):
+        """vit_som.py:107-125 (full gamma, current temperature, no schedule update)."""
+        x, y = batch
+        total = self._forward_losses(x, y, float(self.gamma), float(self.som_layer.current_temperature), want_grad=False)
+        if self.classification:
+            a = self._ctx[1]
+            self._last["acc"] = (a.logits.argmax(dim=-1) == y.view(-1)).float().mean()
+        return total.clone()
+
+    def configure_optimizers(self):
+        """vit_som.py:127-163: AdamW/Adam (lr * batch_size / 256), reference param groups, per-epoch
+        LambdaLR with the warm-up / cosine multiplier floored at min_lr."""
+        hp = self.config["hyperparameters"]
+        opt_hp = hp["optimizer"]
+        groups = param_groups_lrd(self.vit, weight_decay=opt_hp["weight_decay"], layer_decay=opt_hp["layer_decay"])
+        other = list(self.som_layer.parameters())
+        if self.classification:
+            other.extend(list(self.cls_head.parameters()))
+        groups.append({"params": other})
+        if opt_hp["type"] not in ("adamw", "adam"):
+            raise ValueError(f"unsupported optimizer type {opt_hp['type']!r}")
+        optimizer = FusedAdamW(self, groups, lr=opt_hp["lr"] * hp["batch_size"] / 256,
+                               betas=(opt_hp["beta_1"], opt_hp["beta_2"]), adamw=(opt_hp["type"] == "adamw"))
+        if opt_hp["scheduler"] != "cosine_annealing":
+            raise ValueError(f"unsupported scheduler {opt_hp['scheduler']!r}")
+        lr_func = lambda epoch: max(opt_hp["min_lr"], min((epoch + 1) / (opt_hp["warmup_epochs"] + 1e-8),   # noqa: E731
+                                                           0.5 * (math.cos(epoch / hp["total_epochs"] * math.pi) + 1)))
+        scheduler = torch.optim.lr_scheduler.LambdaLR(optimizer, lr_lambda=lr_func)
+        return [optimizer], [scheduler]
+
+    def on_train_end(self):                                             # vit_som.py:165-172
+        print(f"Peak GPU memory usage: {torch.cuda.max_memory_allocated() / 1e9:.4f} GB")
+
+    def get_latent_representation(self, x):
+        """vit_som.py:174-187 (the reference unpacks 4 of 3 values; this returns what it meant)."""
+        with torch.no_grad():
+            cls_token, patches, _ = self.vit(x)
+            return cls_token if self.use_reduced else patches.flatten(start_dim=1)
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+        key = prefix + "iteration"
+        if key in state_dict:
+            self._it = int(state_dict[key])

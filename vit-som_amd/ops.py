@@ -12,6 +12,32 @@ from ._lib import check, lib, ptr, stream
 
 _scratch = {}
 
+# Optional per-op HIP-event timing (bench.py): name -> list of (start_event, end_event) recorded
+# on torch's current stream, which is the stream every kernel here is launched on.
+_timers = {}
+
+
+def enable_timer(name: str):
+    _timers[name] = []
+
+
+def disable_timers():
+    _timers.clear()
+
+
+def timer_ms(name: str):
+    """Average milliseconds per timed call (synchronises)."""
+    ev = _timers.get(name, [])
+    if not ev:
+        return None
+    torch.cuda.synchronize()
+    return sum(a.elapsed_time(b) for a, b in ev) / len(ev), len(ev)
+
+
+def reset_timer(name: str):
+    if name in _timers:
+        _timers[name] = []
+
 
 def scratch(nbytes: int, device) -> torch.Tensor:
     """Grow-only per-device byte scratch (stream-ordered reuse; 256-byte aligned by the allocator)."""
@@ -160,8 +186,16 @@ def bmu_cosine_fwd(x, W, inv_nx, inv_nw, dist: Optional[torch.Tensor], bmu):
     assert W.is_contiguous() and W.shape[1] == L and bmu.dtype == torch.int64 and (dist is None or dist.is_contiguous())
     nbytes = lib.vsom_bmu_cosine_workspace_bytes(B, K, L)
     ws = scratch(nbytes, x.device)
-    check(lib.vsom_bmu_cosine_fwd(ptr(x), _rows(x), ptr(W), ptr(inv_nx), ptr(inv_nw), ptr(dist), ptr(bmu), B, K, L, ptr(ws),
-                                  ws.numel(), stream()), "vsom_bmu_cosine_fwd")
+    rec = _timers.get("bmu_cosine_dots")
+    if rec is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    check(lib.vsom_bmu_cosine_dots(ptr(x), _rows(x), ptr(W), B, K, L, ptr(ws), ws.numel(), stream()), "vsom_bmu_cosine_dots")
+    if rec is not None:
+        e1.record()
+        rec.append((e0, e1))
+    check(lib.vsom_bmu_cosine_finalize(ptr(ws), ws.numel(), ptr(inv_nx), ptr(inv_nw), ptr(dist), ptr(bmu), B, K, L, stream()),
+          "vsom_bmu_cosine_finalize")
     return dist, bmu
 
 
