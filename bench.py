@@ -47,6 +47,8 @@ def cpu_baseline(seconds_budget=25.0):
     Bc = 64
     cfg = c3_config(Bc)
     torch.set_float32_matmul_precision("highest")
+    # one GPU's share of the host is 16 cores; more threads only oversubscribe them
+    torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
     step = O.CPUStep(cfg, seed=0)
     x, y = O.synthetic_batch(step.d, Bc, seed=0)
     n_train, est = 50000, 100000
