@@ -145,7 +145,7 @@ def main():
                                    "L1(recon)+gamma*SOM, AdamW, random-init weights",
                        "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}",
                        "final_loss": round(final_loss, 6)},
-            "roofline": {"kernel": "gemm_f32_kernel<1,1,2,2,2,2,6> (BMU distance pass: X[B,L] . W[K,L]^T, split over L)",
+            "roofline": {"kernel": "gemm_f32_kernel<true,true,1,2,4,1,6,true> (BMU distance pass: X[B,L] . W[K,L]^T, split over L)",
                          "bound": "mfma", "achieved": round(bmu_flops / t_s / 1e12, 3), "peak": F32_MFMA_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(bmu_flops / t_s / 1e12 / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
                          "avg_launch_ms": round(bmu_ms, 4), "launches_timed": bmu_calls,

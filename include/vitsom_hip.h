@@ -43,9 +43,10 @@ const char* vsom_last_error_string(void);
 int vsom_linear_fwd(const float* X, long ldx, const float* W, const float* bias, float* Y, long ldy,
                     int M, int N, int K, vsom_stream_t stream);
 
-/* Ypre = X*W^T + bias ; Yact = gelu_erf(Ypre)   -- mlp.0 + nn.GELU(), vit.py:53-54.
- * Both outputs dense [M,N]. */
-int vsom_linear_gelu_fwd(const float* X, long ldx, const float* W, const float* bias, float* Ypre,
+/* pre = X*W^T + bias ; Yact = gelu_erf(pre) ; Ygrad = gelu_erf'(pre)   -- mlp.0 + nn.GELU(),
+ * vit.py:53-54.  The derivative is saved instead of the pre-activation (it is all the backward
+ * needs, and both come from one exponential).  Both outputs dense [M,N]. */
+int vsom_linear_gelu_fwd(const float* X, long ldx, const float* W, const float* bias, float* Ygrad,
                          float* Yact, int M, int N, int K, vsom_stream_t stream);
 
 /* Y[m] = X[m]*W^T + bias + R[m % r_mod]   -- Linear + residual add (attn.proj vit.py:38,61;
@@ -55,10 +56,10 @@ int vsom_linear_residual_fwd(const float* X, long ldx, const float* W, const flo
                              const float* R, long ldr, int r_mod, float* Y, long ldy, int M, int N,
                              int K, vsom_stream_t stream);
 
-/* dX[M,K] (+)= dY[M,N] * W[N,K]  (optionally  .* gelu_erf'(gelu_pre[M,K]) )
- * -- autograd of nn.Linear w.r.t. its input (and of nn.GELU when gelu_pre != NULL, dense [M,K]). */
+/* dX[M,K] (+)= dY[M,N] * W[N,K]  (optionally  .* gelu_grad[M,K], the Ygrad of vsom_linear_gelu_fwd)
+ * -- autograd of nn.Linear w.r.t. its input (and of nn.GELU when gelu_grad != NULL, dense [M,K]). */
 int vsom_linear_bwd_input(const float* dY, long lddy, const float* W, float* dX, long lddx, int M,
-                          int N, int K, int accumulate, const float* gelu_pre, vsom_stream_t stream);
+                          int N, int K, int accumulate, const float* gelu_grad, vsom_stream_t stream);
 
 /* dW[N,K] = dY[M,N]^T * X[M,K] ;  db[N] = column sums of dY (db may be NULL)
  * -- autograd of nn.Linear w.r.t. weight/bias.  The reduction over the M token rows is split

@@ -1,0 +1,113 @@
+// Lab: minimal NT f32-MFMA GEMM (no bounds checks) with compile-time switches, to find what limits
+// the production kernel at M=33280, N=576, K=192.  C[M,N] = A[M,K] * B[N,K]^T.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <vector>
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// MODE bits: 1 = global loads in loop, 2 = LDS store + barriers, 4 = LDS frag reads, 8 = epilogue stores
+template <int WM, int WN, int WAVES_M, int WAVES_N, int MODE, int OCC>
+__global__ __launch_bounds__(WAVES_M * WAVES_N * 64, OCC) void lab(const float* __restrict__ A, const float* __restrict__ B,
+                                                              float* __restrict__ C, int M, int N, int K) {
+    constexpr int NT = WAVES_M * WAVES_N * 64;
+    constexpr int BM = WAVES_M * WM * 32, BN = WAVES_N * WN * 32;
+    constexpr int RPP = NT / 8;          // rows per pass
+    __shared__ __attribute__((aligned(16))) float lds[(BM + BN) * 36];
+    float* As = lds; float* Bs = lds + BM * 36;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, r = lane & 31, h = lane >> 5;
+    const int wm0 = (wave / WAVES_N) * WM * 32, wn0 = (wave % WAVES_N) * WN * 32;
+    const int tiles_n = N / BN;
+    const int bm0 = (blockIdx.x / tiles_n) * BM, bn0 = (blockIdx.x % tiles_n) * BN;
+    f32x16 acc[WM][WN];
+    for (int i = 0; i < WM; ++i) for (int j = 0; j < WN; ++j) for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+    f32x4 sa[BM / RPP], sb[BN / RPP];
+    const float* ap = A + (long)(bm0 + (t >> 3)) * K + ((t & 7) << 2);
+    const float* bp = B + (long)(bn0 + (t >> 3)) * K + ((t & 7) << 2);
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int p = 0; p < BM / RPP; ++p) sa[p] = *(const f32x4*)(ap + (long)p * RPP * K + k0);
+#pragma unroll
+        for (int p = 0; p < BN / RPP; ++p) sb[p] = *(const f32x4*)(bp + (long)p * RPP * K + k0);
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int p = 0; p < BM / RPP; ++p) *(f32x4*)(As + (p * RPP + (t >> 3)) * 36 + ((t & 7) << 2)) = sa[p];
+#pragma unroll
+        for (int p = 0; p < BN / RPP; ++p) *(f32x4*)(Bs + (p * RPP + (t >> 3)) * 36 + ((t & 7) << 2)) = sb[p];
+    };
+    gload(0); lstore(); __syncthreads();
+    const int nk = K / 32;
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool more = kt + 1 < nk;
+        if ((MODE & 1) && more) gload((kt + 1) * 32);
+#pragma unroll
+        for (int kb = 0; kb < 32; kb += 8) {
+            f32x4 a[WM], b[WN];
+#pragma unroll
+            for (int i = 0; i < WM; ++i) {
+                if (MODE & 4) a[i] = *(const f32x4*)(As + (wm0 + i * 32 + r) * 36 + kb + 4 * h);
+                else a[i] = f32x4{1.f + kb, 2.f, 3.f, 4.f + lane};
+            }
+#pragma unroll
+            for (int j = 0; j < WN; ++j) {
+                if (MODE & 4) b[j] = *(const f32x4*)(Bs + (wn0 + j * 32 + r) * 36 + kb + 4 * h);
+                else b[j] = f32x4{1.f, 2.f + kb, 3.f + lane, 4.f};
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int i = 0; i < WM; ++i)
+#pragma unroll
+                    for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
+        }
+        if (MODE & 2) {
+            __syncthreads();
+            if (more) { lstore(); __syncthreads(); }
+        }
+    }
+    if (MODE & 8) {
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const int m = bm0 + wm0 + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * h, n = bn0 + wn0 + j * 32 + r;
+                    C[(long)m * N + n] = acc[i][j][v];
+                }
+    } else {
+        float s = 0; for (int i = 0; i < WM; ++i) for (int j = 0; j < WN; ++j) for (int v = 0; v < 16; ++v) s += acc[i][j][v];
+        if (s == 123.456f) C[t] = s;
+    }
+}
+template <int WM, int WN, int WAVES_M, int WAVES_N, int MODE, int OCC>
+void run(const char* tag, const float* A, const float* B, float* C, int M, int N, int K) {
+    constexpr int BM = WAVES_M * WM * 32, BN = WAVES_N * WN * 32;
+    dim3 grid((M / BM) * (N / BN));
+    auto go = [&]() { hipLaunchKernelGGL((lab<WM, WN, WAVES_M, WAVES_N, MODE, OCC>), grid, dim3(WAVES_M * WAVES_N * 64), 0, 0, A, B, C, M, N, K); };
+    go(); hipDeviceSynchronize();
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    float best = 1e9;
+    for (int r = 0; r < 5; ++r) { hipEventRecord(e0); for (int i = 0; i < 5; ++i) go(); hipEventRecord(e1); hipEventSynchronize(e1); float ms; hipEventElapsedTime(&ms, e0, e1); if (ms / 5 < best) best = ms / 5; }
+    printf("%-28s tile %dx%d waves %dx%d mode %2d occ %d: %7.1f us  %6.1f TF\n", tag, BM, BN, WAVES_M, WAVES_N, MODE, OCC, best * 1e3, 2.0 * M * N * K / best / 1e9);
+}
+int main() {
+    const int M = 33280, N = 576, K = 192;
+    float *A, *B, *C; hipMalloc(&A, (size_t)M * K * 4); hipMalloc(&B, (size_t)N * K * 4); hipMalloc(&C, (size_t)M * N * 4);
+    std::vector<float> h((size_t)M * K); for (size_t i = 0; i < h.size(); ++i) h[i] = (float)(((i * 2654435761u) >> 8) & 0xffff) / 65536.f - 0.5f;
+    hipMemcpy(A, h.data(), h.size() * 4, hipMemcpyHostToDevice); hipMemcpy(B, h.data(), (size_t)N * K * 4, hipMemcpyHostToDevice);
+    run<1, 2, 4, 1, 0, 1>("mfma only", A, B, C, M, N, K);
+    run<1, 2, 4, 1, 4, 1>("+lds reads", A, B, C, M, N, K);
+    run<1, 2, 4, 1, 6, 1>("+lds reads+store/barrier", A, B, C, M, N, K);
+    run<1, 2, 4, 1, 7, 1>("+global loads", A, B, C, M, N, K);
+    run<1, 2, 4, 1, 15, 1>("full", A, B, C, M, N, K);
+    run<1, 2, 4, 1, 8, 1>("mfma+epilogue", A, B, C, M, N, K);
+    run<1, 2, 4, 1, 15, 2>("full occ2", A, B, C, M, N, K);
+    run<1, 2, 4, 1, 15, 3>("full occ3", A, B, C, M, N, K);
+    run<1, 2, 4, 1, 15, 4>("full occ4", A, B, C, M, N, K);
+    run<2, 2, 2, 1, 15, 2>("full 2 waves of 64x64", A, B, C, M, N, K);
+    run<2, 2, 2, 1, 15, 3>("full 2 waves of 64x64", A, B, C, M, N, K);
+    run<2, 2, 2, 1, 0, 1>("mfma only 2 waves 64x64", A, B, C, M, N, K);
+    return 0;
+}

@@ -46,13 +46,23 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
-__device__ __forceinline__ float gelu_erf(float x) {           // nn.GELU() default (exact erf)
-    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
-}
-__device__ __forceinline__ float gelu_erf_grad(float x) {
-    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
-    const float pdf = 0.39894228040143267794f * expf(-0.5f * x * x);
-    return cdf + x * pdf;
+// nn.GELU() (exact-erf form) and its derivative from ONE exponential:
+//   gelu(x) = x Phi(x),  gelu'(x) = Phi(x) + x phi(x),  Phi(x) = (1 + erf(x/sqrt2))/2,
+//   phi(x) = exp(-x^2/2)/sqrt(2 pi)  -- and erf(x/sqrt2) = 1 - poly(t) exp(-x^2/2) with the SAME
+// exponential (Abramowitz-Stegun 7.1.26, |erf error| <= 1.5e-7, i.e. <= 7.5e-8 on Phi: below
+// fp32 rounding of the surrounding GEMMs and far inside the 1e-4 parity bar).
+__device__ __forceinline__ void gelu_erf_both(float x, float& act, float& grad) {
+    const float ax = fabsf(x);
+    const float e = __expf(-0.5f * x * x);
+    const float t = __frcp_rn(fmaf(0.3275911f * 0.70710678118654752440f, ax, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float erfc_abs = p * t * e;                    // 1 - erf(|x|/sqrt2)
+    const float cdf = (x >= 0.f) ? 1.0f - 0.5f * erfc_abs : 0.5f * erfc_abs;
+    act = x * cdf;
+    grad = fmaf(x * 0.39894228040143267794f, e, cdf);
 }
 
 // XCD-aware bijective block remap (MI355X: 8 XCDs, blocks dealt round-robin).  Blocks that share

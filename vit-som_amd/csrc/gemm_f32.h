@@ -9,10 +9,12 @@
 //   input    grad    dX = dY W      : A_KC, !B_KC   ("NN")
 //   weight   grad    dW = dY^T X    : !A_KC, !B_KC  ("TN", split over the reduction -> slabs)
 //
-// Tiling: 256 threads = 4 waves; block tile BM x BN (128x128 or 128x64), BK = 32; each wave owns
-// WM x WN tiles of 32x32 (16 accumulator VGPRs each).  Operand tiles are staged global ->
+// Tiling: 256 threads = 4 waves; block tile 128 x 64, BK = 32; each wave owns WM x WN = 1 x 2
+// tiles of 32x32 (16 accumulator VGPRs each).  Operand tiles are staged global ->
 // registers -> LDS (one LDS buffer, next tile's global loads in flight during the MFMAs); with
-// f32 MFMA at 64 cycles per instruction the 2-4 co-resident workgroups per CU cover the staging.
+// f32 MFMA at 64 cycles per instruction the 2-3 co-resident workgroups per CU cover the staging.
+// One workgroup per output tile (a persistent / cross-tile-prefetch variant measured no faster:
+// hipcc then shuttles the accumulators AGPR<->VGPR every k-tile and drains vmcnt early).
 // LDS images: k-contiguous tiles are [rows][36] (row stride 144 B: conflict-free ds_read_b128 of
 // 4 consecutive k per lane), k-strided tiles are [32][cols+4] (ds_read_b32 across 32 consecutive
 // columns).  Lane l = (r = l & 31, h = l >> 5) feeds MFMA step s of an 8-deep group with
@@ -25,10 +27,10 @@ namespace vsom {
 enum Epi : int {
     EPI_NONE = 0,       // v = alpha*acc (+ C if accumulate)
     EPI_BIAS = 1,       // v = acc + bias[n]
-    EPI_BIAS_GELU = 2,  // pre = acc + bias[n]; C = pre; C2 = gelu(pre)
+    EPI_BIAS_GELU = 2,  // pre = acc + bias[n]; C = gelu'(pre); C2 = gelu(pre)
     EPI_BIAS_RES = 3,   // v = acc + bias[n] + R[(m % r_mod + r_off)*ldr + n]; output row map
     EPI_ROWAXPY = 4,    // v = acc + rowscale[m]*R[m*ldr + n] (+ C if accumulate)
-    EPI_GELU_BWD = 5,   // v = acc * gelu'(R[m*ldr + n]) (+ C if accumulate)
+    EPI_GELU_BWD = 5,   // v = acc * R[m*ldr + n] (R = gelu'(pre) saved by the forward) (+ C if accumulate)
     EPI_SLAB = 6,       // split-k partial: slab[z][m*N + n] = acc; optional column sums of A
 };
 
@@ -50,13 +52,65 @@ struct GemmP {
     float* slab; long slab_stride;   // EPI_SLAB
     float* slab_bias; long slab_bias_stride;   // per-split column sums of A (bias gradient), or null
     int a_vec, b_vec;            // 16-byte vector loads legal for A / B
+    unsigned a_bytes, b_bytes;   // extent of A / B for the bounds-checked buffer loads (FAST path)
 };
 
 template <int R_>
 struct StageRegs { f32x4 v[R_ / 32]; };
 
+constexpr unsigned OOB = 0xFFFFFFF0u;      // byte offset past any buffer: raw buffer loads return 0
+
+__device__ __forceinline__ f32x4 bload4(__amdgpu_buffer_rsrc_t rsrc, unsigned off) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)off, 0, 0));
+}
+
 // ---- global -> register staging ------------------------------------------------------------
+// FAST path: 16-byte hardware-bounds-checked buffer loads.  Each thread's byte offsets into the
+// operand are computed ONCE per output tile (OOB when its row / column is outside the matrix);
+// inside the k-loop a load costs one add and one select.
 // k-contiguous tile: ROWS x 32, thread t loads float4 at (row = p*32 + t/8, k = (t%8)*4)
+template <int ROWS>
+struct OffKC { unsigned off[ROWS / 32]; };
+template <int ROWS>
+__device__ __forceinline__ void init_kc(OffKC<ROWS>& o, long ld, int row0, int nrows, int t) {
+#pragma unroll
+    for (int p = 0; p < ROWS / 32; ++p) {
+        const int row = row0 + p * 32 + (t >> 3);
+        o.off[p] = (row < nrows) ? (unsigned)(((long)row * ld + ((t & 7) << 2)) << 2) : OOB;
+    }
+}
+template <int ROWS>
+__device__ __forceinline__ void load_kc_fast(StageRegs<ROWS>& s, __amdgpu_buffer_rsrc_t rsrc, const OffKC<ROWS>& o,
+                                             int k0, int K, int t) {
+    const bool kok = k0 + ((t & 7) << 2) < K;
+    const unsigned kbytes = (unsigned)k0 << 2;
+#pragma unroll
+    for (int p = 0; p < ROWS / 32; ++p) s.v[p] = bload4(rsrc, (kok && o.off[p] != OOB) ? o.off[p] + kbytes : OOB);
+}
+// k-strided tile: 32 x COLS, thread t loads float4 at (k = p*KPP + t/(COLS/4), col = (t%(COLS/4))*4)
+template <int COLS>
+struct OffKS { unsigned col; unsigned ldb4; };
+template <int COLS>
+__device__ __forceinline__ void init_ks(OffKS<COLS>& o, long ld, int col0, int ncols, int t) {
+    constexpr int TPR = COLS / 4;
+    const int col = col0 + ((t % TPR) << 2);
+    o.col = (col < ncols) ? (unsigned)col << 2 : OOB;
+    o.ldb4 = (unsigned)ld << 2;
+}
+template <int COLS>
+__device__ __forceinline__ void load_ks_fast(StageRegs<COLS>& s, __amdgpu_buffer_rsrc_t rsrc, const OffKS<COLS>& o,
+                                             int k0, int K, int t, int seg, int stride, int off0) {
+    constexpr int TPR = COLS / 4;
+    constexpr int KPP = 256 / TPR;
+    const int kk = k0 + t / TPR;
+#pragma unroll
+    for (int p = 0; p < COLS / 32; ++p) {
+        const int k = kk + p * KPP;
+        const unsigned row = seg ? (unsigned)((k / seg) * stride + off0 + (k % seg)) : (unsigned)k;
+        s.v[p] = bload4(rsrc, (k < K && o.col != OOB) ? row * o.ldb4 + o.col : OOB);
+    }
+}
+// generic (any alignment / ragged K) variants
 template <int ROWS>
 __device__ __forceinline__ void load_kc(StageRegs<ROWS>& s, const float* __restrict__ base, long ld,
                                         int row0, int nrows, int k0, int K, int vec, int t) {
@@ -85,7 +139,6 @@ __device__ __forceinline__ void store_kc(const StageRegs<ROWS>& s, float* lds, i
     for (int p = 0; p < ROWS / 32; ++p)
         *reinterpret_cast<f32x4*>(lds + (p * 32 + (t >> 3)) * 36 + ((t & 7) << 2)) = s.v[p];
 }
-// k-strided tile: 32 x COLS, thread t loads float4 at (k = p*KPP + t/(COLS/4), col = (t%(COLS/4))*4)
 template <int COLS>
 __device__ __forceinline__ void load_ks(StageRegs<COLS>& s, const float* __restrict__ base, long ld,
                                         int col0, int ncols, int k0, int K, int vec, int t, int seg,
@@ -121,7 +174,7 @@ __device__ __forceinline__ void store_ks(const StageRegs<COLS>& s, float* lds, i
         *reinterpret_cast<f32x4*>(lds + (p * KPP + t / TPR) * (COLS + 4) + ((t % TPR) << 2)) = s.v[p];
 }
 
-template <bool A_KC, bool B_KC, int WM, int WN, int WAVES_M, int WAVES_N, int EPI>
+template <bool A_KC, bool B_KC, int WM, int WN, int WAVES_M, int WAVES_N, int EPI, bool FAST>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmP g) {
     constexpr int BM = WAVES_M * WM * 32;
     constexpr int BN = WAVES_N * WN * 32;
@@ -138,8 +191,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmP g) {
     const int wn0 = (wave % WAVES_N) * (WN * 32);
 
     const int tiles_n = (g.N + BN - 1) / BN;
-    const int nblk = gridDim.x;
-    const int bid = xcd_remap(blockIdx.x, nblk);
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
     const int bm0 = (bid / tiles_n) * BM;
     const int bn0 = (bid % tiles_n) * BN;
     const int z = blockIdx.z;
@@ -158,16 +210,31 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmP g) {
             for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
 
     float colsum = 0.f;                       // EPI_SLAB bias partial (thread t < BM owns A column t)
-    const bool want_colsum = (EPI == EPI_SLAB) && !A_KC && g.slab_bias != nullptr && (bid % tiles_n) == 0;
+    const bool want_colsum = (EPI == EPI_SLAB) && !A_KC && g.slab_bias != nullptr && bn0 == 0;
 
     StageRegs<BM> sa;
     StageRegs<BN> sb;
+    __amdgpu_buffer_rsrc_t rsA, rsB;
+    OffKC<BM> oa_kc; OffKS<BM> oa_ks; OffKC<BN> ob_kc; OffKS<BN> ob_ks;
+    if constexpr (FAST) {
+        rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.A), 0, (int)g.a_bytes, 0x00020000);
+        rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.B), 0, (int)g.b_bytes, 0x00020000);
+        if constexpr (A_KC) init_kc<BM>(oa_kc, g.lda, bm0, g.M, t); else init_ks<BM>(oa_ks, g.lda, bm0, g.M, t);
+        if constexpr (B_KC) init_kc<BN>(ob_kc, g.ldb, bn0, g.N, t); else init_ks<BN>(ob_ks, g.ldb, bn0, g.N, t);
+    }
     auto gload = [&](int kt) {
         const int k0 = kt << 5;
-        if constexpr (A_KC) load_kc<BM>(sa, g.A, g.lda, bm0, g.M, k0, g.K, g.a_vec, t);
-        else load_ks<BM>(sa, g.A, g.lda, bm0, g.M, k0, g.K, g.a_vec, t, g.a_seg, g.a_stride, g.a_off);
-        if constexpr (B_KC) load_kc<BN>(sb, g.B, g.ldb, bn0, g.N, k0, g.K, g.b_vec, t);
-        else load_ks<BN>(sb, g.B, g.ldb, bn0, g.N, k0, g.K, g.b_vec, t, 0, 0, 0);
+        if constexpr (FAST) {
+            if constexpr (A_KC) load_kc_fast<BM>(sa, rsA, oa_kc, k0, g.K, t);
+            else load_ks_fast<BM>(sa, rsA, oa_ks, k0, g.K, t, g.a_seg, g.a_stride, g.a_off);
+            if constexpr (B_KC) load_kc_fast<BN>(sb, rsB, ob_kc, k0, g.K, t);
+            else load_ks_fast<BN>(sb, rsB, ob_ks, k0, g.K, t, 0, 0, 0);
+        } else {
+            if constexpr (A_KC) load_kc<BM>(sa, g.A, g.lda, bm0, g.M, k0, g.K, g.a_vec, t);
+            else load_ks<BM>(sa, g.A, g.lda, bm0, g.M, k0, g.K, g.a_vec, t, g.a_seg, g.a_stride, g.a_off);
+            if constexpr (B_KC) load_kc<BN>(sb, g.B, g.ldb, bn0, g.N, k0, g.K, g.b_vec, t);
+            else load_ks<BN>(sb, g.B, g.ldb, bn0, g.N, k0, g.K, g.b_vec, t, 0, 0, 0);
+        }
     };
     auto lstore = [&]() {
         if constexpr (A_KC) store_kc<BM>(sa, As, t); else store_ks<BM>(sa, As, t);
@@ -228,49 +295,75 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmP g) {
     }
 
     // ---------------------------------------------------------------- epilogue
+    // accumulator register v of a 32x32 tile holds row (v&3) + 8*(v>>2) + 4*h, column r: walk the
+    // rows with pointer increments (no per-element index arithmetic); the rare output-row map
+    // (patch embedding) takes the indexed path.
     if constexpr (EPI == EPI_SLAB) {
         if (want_colsum && t < BM && bm0 + t < g.M) g.slab_bias[(long)z * g.slab_bias_stride + bm0 + t] = colsum;
     }
+    const bool rowmap = (EPI == EPI_BIAS_RES) && g.c_seg != 0;
 #pragma unroll
     for (int i = 0; i < WM; ++i) {
 #pragma unroll
         for (int j = 0; j < WN; ++j) {
             const int n = bn0 + wn0 + j * 32 + r;
             if (n >= g.N) continue;
+            const int mb = bm0 + wm0 + i * 32 + 4 * h;
             float bn = 0.f;
-            if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RES)
-                bn = g.bias ? g.bias[n] : 0.f;
+            if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RES) bn = g.bias ? g.bias[n] : 0.f;
+            if constexpr (EPI == EPI_SLAB) {
+                float* dst = g.slab + (long)z * g.slab_stride + (long)mb * g.N + n;
 #pragma unroll
-            for (int v = 0; v < 16; ++v) {
-                const int m = bm0 + wm0 + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
-                if (m >= g.M) continue;
-                const float a = acc[i][j][v];
-                if constexpr (EPI == EPI_SLAB) {
-                    g.slab[(long)z * g.slab_stride + (long)m * g.N + n] = a;
-                } else {
-                    const long orow = g.c_seg ? (long)(m / g.c_seg) * g.c_stride + g.c_off + (m % g.c_seg) : (long)m;
-                    float* dst = g.C + orow * g.ldc + n;
+                for (int v = 0; v < 16; ++v) {
+                    const int dm = (v & 3) + 8 * (v >> 2);
+                    if (mb + dm < g.M) dst[(long)dm * g.N] = acc[i][j][v];
+                }
+            } else if (rowmap) {
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const int m = mb + (v & 3) + 8 * (v >> 2);
+                    if (m >= g.M) continue;
+                    const long orow = (long)(m / g.c_seg) * g.c_stride + g.c_off + (m % g.c_seg);
+                    const long rr = (long)(m % g.r_mod) + g.r_off;
+                    g.C[orow * g.ldc + n] = acc[i][j][v] + bn + g.R[rr * g.ldr + n];
+                }
+            } else {
+                float* dst = g.C + (long)mb * g.ldc + n;
+                const float* rsrc = nullptr;
+                float* dst2 = nullptr;
+                if constexpr (EPI == EPI_ROWAXPY || EPI == EPI_GELU_BWD) rsrc = g.R + (long)mb * g.ldr + n;
+                if constexpr (EPI == EPI_BIAS_GELU) dst2 = g.C2 + (long)mb * g.ldc2 + n;
+                const bool plain_res = (EPI == EPI_BIAS_RES) && g.r_mod >= g.M && g.r_off == 0;
+                if constexpr (EPI == EPI_BIAS_RES) rsrc = g.R + (long)mb * g.ldr + n;
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const int dm = (v & 3) + 8 * (v >> 2);
+                    const int m = mb + dm;
+                    if (m >= g.M) continue;
+                    const float a = acc[i][j][v];
+                    float* d = dst + (long)dm * g.ldc;
                     if constexpr (EPI == EPI_NONE) {
                         float val = g.alpha * a;
-                        if (g.accumulate) val += *dst;
-                        *dst = val;
+                        if (g.accumulate) val += *d;
+                        *d = val;
                     } else if constexpr (EPI == EPI_BIAS) {
-                        *dst = a + bn;
+                        *d = a + bn;
                     } else if constexpr (EPI == EPI_BIAS_GELU) {
-                        const float pre = a + bn;
-                        *dst = pre;
-                        g.C2[(long)m * g.ldc2 + n] = gelu_erf(pre);
+                        float act, grad;
+                        gelu_erf_both(a + bn, act, grad);
+                        *d = grad;
+                        dst2[(long)dm * g.ldc2] = act;
                     } else if constexpr (EPI == EPI_BIAS_RES) {
-                        const long rr = (long)(m % g.r_mod) + g.r_off;
-                        *dst = a + bn + g.R[rr * g.ldr + n];
+                        const float rv = plain_res ? rsrc[(long)dm * g.ldr] : g.R[((long)(m % g.r_mod) + g.r_off) * g.ldr + n];
+                        *d = a + bn + rv;
                     } else if constexpr (EPI == EPI_ROWAXPY) {
-                        float val = a + g.rowscale[m] * g.R[(long)m * g.ldr + n];
-                        if (g.accumulate) val += *dst;
-                        *dst = val;
+                        float val = a + g.rowscale[m] * rsrc[(long)dm * g.ldr];
+                        if (g.accumulate) val += *d;
+                        *d = val;
                     } else if constexpr (EPI == EPI_GELU_BWD) {
-                        float val = a * gelu_erf_grad(g.R[(long)m * g.ldr + n]);
-                        if (g.accumulate) val += *dst;
-                        *dst = val;
+                        float val = a * rsrc[(long)dm * g.ldr];
+                        if (g.accumulate) val += *d;
+                        *d = val;
                     }
                 }
             }
@@ -284,6 +377,8 @@ int linear_bwd_weight_impl(const float* dY, long lddy, const float* X, long ldx,
                            int K, int a_seg, int a_stride, int a_off, void* ws, size_t ws_bytes,
                            hipStream_t stream);
 int reduce_slabs_internal(const float* slabs, long stride, int nslabs, float* out, long n, hipStream_t stream);
+int reduce_slabs2_internal(const float* slabs, long stride, int nslabs, float* out1, long n1, float* out2, long off2,
+                           long n2, hipStream_t stream);
 int sum_partials(const float* part, int n, float* out, hipStream_t stream);
 
 }  // namespace vsom

@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
 
 static int ln_bwd_blocks(int rows) {
     int b = cdiv(rows, 64);          // >= 16 rows per wave
-    if (b > 1024) b = 1024;
+    if (b > 512) b = 512;
     if (b < 1) b = 1;
     return b;
 }
@@ -154,9 +154,7 @@ int vsom_layernorm_bwd(const float* dY, const float* X, const float* mean, const
         hipLaunchKernelGGL(layernorm_bwd_kernel<16>, dim3(nblk), dim3(256), shmem, stream, dY, X, mean, rstd, gamma, resid, dX, part, rows, cols);
     int rc = hip_status(hipGetLastError(), "layernorm_bwd_kernel");
     if (rc) return rc;
-    rc = reduce_slabs_internal(part, 2L * cols, nblk, dgamma, cols, stream);
-    if (rc) return rc;
-    return reduce_slabs_internal(part + cols, 2L * cols, nblk, dbeta, cols, stream);
+    return reduce_slabs2_internal(part, 2L * cols, nblk, dgamma, cols, dbeta, cols, cols, stream);
 }
 
 }  // extern "C"

@@ -67,8 +67,7 @@ __global__ __launch_bounds__(256) void bmu_finalize_kernel(const float* __restri
 }
 
 static int bmu_splits(int B, int K, int L) {
-    const int BN = 128;
-    const int tiles = cdiv(B, 128) * cdiv(K, BN);
+    const int tiles = cdiv(B, 128) * cdiv(K, 64);
     const int ktiles = cdiv(L, 32);
     int s = cdiv(768, tiles);               // ~3 workgroups per CU
     if (s > ktiles / 8) s = ktiles / 8;     // keep >= 8 k-tiles (256 deep) per split

@@ -310,7 +310,7 @@ class ViTAutoencoder(nn.Module):
         da = a.da[:T * dim].view(T, dim)
         dqkv = a.dqkv[:T * 3 * dim].view(T, 3 * dim)
         ops.linear_bwd_weight(gout, L.hact, G(f"{prefix}.mlp.2.weight"), G(f"{prefix}.mlp.2.bias"))
-        ops.linear_bwd_input(gout, blk.mlp["2"].weight, dh, gelu_pre=L.hpre)
+        ops.linear_bwd_input(gout, blk.mlp["2"].weight, dh, gelu_grad=L.hpre)
         ops.linear_bwd_weight(dh, L.a2, G(f"{prefix}.mlp.0.weight"), G(f"{prefix}.mlp.0.bias"))
         ops.linear_bwd_input(dh, blk.mlp["0"].weight, da)
         ops.layernorm_bwd(da, L.x1, L.mean2, L.rstd2, blk.norm2.weight, gout, g1, G(f"{prefix}.norm2.weight"),

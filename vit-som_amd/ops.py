@@ -73,7 +73,9 @@ def linear_fwd(x, W, bias, out):
     return out
 
 
-def linear_gelu_fwd(x, W, bias, pre, act):
+def linear_gelu_fwd(x, W, bias, grad, act):
+    """grad <- gelu'(x W^T + b), act <- gelu(x W^T + b)."""
+    pre = grad
     M, K = x.shape
     N = W.shape[0]
     _f32(x, "x"); _f32(W, "W")
@@ -92,7 +94,8 @@ def linear_residual_fwd(x, W, bias, R, r_mod, out):
     return out
 
 
-def linear_bwd_input(dy, W, dx, accumulate=False, gelu_pre=None):
+def linear_bwd_input(dy, W, dx, accumulate=False, gelu_grad=None):
+    gelu_pre = gelu_grad
     M, N = dy.shape
     K = W.shape[1]
     _f32(dy, "dy"); _f32(W, "W"); _f32(dx, "dx")
