@@ -380,5 +380,6 @@ int reduce_slabs_internal(const float* slabs, long stride, int nslabs, float* ou
 int reduce_slabs2_internal(const float* slabs, long stride, int nslabs, float* out1, long n1, float* out2, long off2,
                            long n2, hipStream_t stream);
 int sum_partials(const float* part, int n, float* out, hipStream_t stream);
+int choose_splits(int tiles, int ktiles, int max_splits);
 
 }  // namespace vsom

@@ -2,7 +2,6 @@
 #include "gemm_f32.h"
 
 #include <stdarg.h>
-#include <stdlib.h>
 
 namespace vsom {
 
@@ -145,16 +144,42 @@ int reduce_slabs_internal(const float* slabs, long stride, int nslabs, float* ou
     return reduce_slabs2_internal(slabs, stride, nslabs, out, n, nullptr, 0, 0, stream);
 }
 
-// split count for the weight-gradient reduction over M token rows
+// Split count for a reduction-split GEMM (weight gradients over the token rows, the BMU pass over
+// L).  Workgroups are resident 3 per CU (register budget of the 128x64 tile), so a launch runs in
+// ceil(tiles*s / slots) rounds of ceil(ktiles/s) k-tiles each; pick the s that minimises
+// rounds x (k-tiles per workgroup + fixed per-workgroup cost) + the slab-reduction cost.
+int choose_splits(int tiles, int ktiles, int max_splits) {
+    static int slots = 0;
+    if (!slots) {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) {
+            hipDeviceProp_t p;
+            if (hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0) cus = p.multiProcessorCount;
+        }
+        slots = 3 * cus;
+    }
+    if (max_splits > ktiles) max_splits = ktiles;
+    if (max_splits < 1) max_splits = 1;
+    // measured relative MFMA efficiency with 1 / 2 / 3 co-resident workgroups per CU
+    static const double eff[4] = {1.0, 0.64, 0.80, 1.0};
+    const int per_cu = slots / 3;
+    double best = 1e30;
+    int best_s = 1;
+    for (int s = 1; s <= max_splits; ++s) {
+        const int per = cdiv(ktiles, s);
+        if (cdiv(ktiles, per) != s) continue;            // only canonical split counts
+        const long blocks = (long)tiles * s;
+        const long full = blocks / slots;                // rounds with every slot taken
+        const long rest = blocks - full * slots;
+        const int share = (int)((rest + per_cu - 1) / per_cu);          // 0..3 workgroups per CU in the last round
+        const double passes = 3.0 * full + (share ? share / eff[share] : 0.0);
+        const double cost = passes * (per + 3.5) + 0.003 * tiles * s;   // + slab reduction
+        if (cost < best) { best = cost; best_s = s; }
+    }
+    return best_s;
+}
 static int bwd_weight_splits(int M, int N, int K) {
-    const int tiles = cdiv(N, 128) * cdiv(K, 64);
-    const int ktiles = cdiv(M, 32);
-    int s = cdiv(512, tiles);               // ~2 workgroups per CU (what the register budget admits)
-    if (s > ktiles) s = ktiles;
-    if (s > 32) s = 32;
-    if (s < 1) s = 1;
-    const int per = cdiv(ktiles, s);
-    return cdiv(ktiles, per);
+    return choose_splits(cdiv(N, 128) * cdiv(K, 64), cdiv(M, 32), 128);
 }
 static long pad4(long n) { return (n + 3) & ~3L; }
 

@@ -67,14 +67,7 @@ __global__ __launch_bounds__(256) void bmu_finalize_kernel(const float* __restri
 }
 
 static int bmu_splits(int B, int K, int L) {
-    const int tiles = cdiv(B, 128) * cdiv(K, 64);
-    const int ktiles = cdiv(L, 32);
-    int s = cdiv(768, tiles);               // ~3 workgroups per CU
-    if (s > ktiles / 8) s = ktiles / 8;     // keep >= 8 k-tiles (256 deep) per split
-    if (s > 32) s = 32;
-    if (s < 1) s = 1;
-    const int per = cdiv(ktiles, s);
-    return cdiv(ktiles, per);
+    return choose_splits(cdiv(B, 128) * cdiv(K, 64), cdiv(L, 32), 32);
 }
 
 // ------------------------------------------------------------------ neighbourhood / loss / coefficients
