@@ -604,6 +604,7 @@ class ViTSOM(_Base):
         self._n_train: Optional[int] = None
         self._est_steps: Optional[int] = None
         self.world_size, self.rank = 1, 0
+        self._grads_reduced = False
         self._last: Dict[str, torch.Tensor] = {}
         self.arena: Optional[ParamArena] = None
         if device is None:
@@ -768,6 +769,7 @@ class ViTSOM(_Base):
     def _backward(self):
         """All backward kernels; overwrites the whole gradient arena (no accumulation)."""
         x, a, s = self._ctx
+        self._grads_reduced = False
         Gv = self._G("vit.")
         if self.classification:
             ops.fill(a.d_xe, 0.0)
@@ -791,11 +793,20 @@ class ViTSOM(_Base):
 
     # -- data-parallel exchange ----------------------------------------------------------------
     def allreduce_gradients(self):
-        """Sum the whole gradient arena (ViT grads + prototype accumulators) across ranks with one
-        RCCL all-reduce over xGMI; AdamW divides by world_size."""
-        if self.world_size > 1:
-            import torch.distributed as dist
-            dist.all_reduce(self.arena.grads, op=dist.ReduceOp.SUM)
+        """Sum the whole gradient arena (ViT grads + prototype accumulators) across ranks with ONE
+        all-reduce (RCCL over xGMI under the "nccl" backend); AdamW divides by world_size.  Under the
+        gloo backend (CPU rehearsal of the N > 1 path) device tensors are staged through the host."""
+        if self.world_size <= 1 or self._grads_reduced:
+            return
+        self._grads_reduced = True            # idempotent until the next backward pass
+        import torch.distributed as dist
+        g = self.arena.grads
+        if g.is_cuda and dist.get_backend() == "gloo":
+            host = g.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM)
+            g.copy_(host)
+        else:
+            dist.all_reduce(g, op=dist.ReduceOp.SUM)
 
     # -- reference API ---------------------------------------------------------------------------
     def _schedules_for_step(self):
