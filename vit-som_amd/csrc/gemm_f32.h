@@ -51,6 +51,7 @@ struct GemmP {
     float alpha; int accumulate;
     float* slab; long slab_stride;   // EPI_SLAB
     float* slab_bias; long slab_bias_stride;   // per-split column sums of A (bias gradient), or null
+    int n_major;                 // tile order inside a split: 1 = consecutive ids walk the m-tiles of one n-tile
     int a_vec, b_vec;            // 16-byte vector loads legal for A / B
     unsigned a_bytes, b_bytes;   // extent of A / B for the bounds-checked buffer loads (FAST path)
 };
@@ -190,11 +191,20 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmP g) {
     const int wm0 = (wave / WAVES_N) * (WM * 32);
     const int wn0 = (wave % WAVES_N) * (WN * 32);
 
+    // 1-D grid of (split, tile) pairs.  After the XCD remap each XCD owns a CONTIGUOUS range of
+    // logical ids; split-major order gives every XCD its own slice of the reduction range (it
+    // reads that slice of both operands once, its private L2 serves the re-use), and inside a
+    // split tiles are ordered so that neighbours share the LARGER operand's panel.
     const int tiles_n = (g.N + BN - 1) / BN;
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int bm0 = (bid / tiles_n) * BM;
-    const int bn0 = (bid % tiles_n) * BN;
-    const int z = blockIdx.z;
+    const int tiles_m = (g.M + BM - 1) / BM;
+    const int ntiles = tiles_m * tiles_n;
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int z = lid / ntiles;
+    const int rem = lid - z * ntiles;
+    const int tm = g.n_major ? rem % tiles_m : rem / tiles_n;
+    const int tn = g.n_major ? rem / tiles_m : rem % tiles_n;
+    const int bm0 = tm * BM;
+    const int bn0 = tn * BN;
 
     const int ktiles = (g.K + 31) >> 5;
     const int kt_begin = z * g.ktiles_per_split;
@@ -380,6 +390,6 @@ int reduce_slabs_internal(const float* slabs, long stride, int nslabs, float* ou
 int reduce_slabs2_internal(const float* slabs, long stride, int nslabs, float* out1, long n1, float* out2, long off2,
                            long n2, hipStream_t stream);
 int sum_partials(const float* part, int n, float* out, hipStream_t stream);
-int choose_splits(int tiles, int ktiles, int max_splits);
+int choose_splits(int tiles, int ktiles, int max_splits, bool prefer_xcd_multiple = false);
 
 }  // namespace vsom

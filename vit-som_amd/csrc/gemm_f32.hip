@@ -23,7 +23,7 @@ template <bool A_KC, bool B_KC, int EPI>
 static int launch_t(GemmP& g, int splits, hipStream_t stream) {
     const int BM = 128, BN = 64;
     const int tiles = cdiv(g.M, BM) * cdiv(g.N, BN);
-    dim3 grid(tiles, 1, splits), block(256);
+    dim3 grid(tiles * splits, 1, 1), block(256);
     // extent of each operand in bytes; rows of a k-strided A may be remapped (a_seg)
     const long a_rows = A_KC ? g.M : (g.a_seg ? (long)((g.K - 1) / g.a_seg) * g.a_stride + g.a_off + (g.K - 1) % g.a_seg + 1 : g.K);
     const long a_cols = A_KC ? g.K : g.M;
@@ -31,6 +31,7 @@ static int launch_t(GemmP& g, int splits, hipStream_t stream) {
     const long ab = operand_bytes(a_rows, g.lda, a_cols), bb = operand_bytes(b_rows, g.ldb, b_cols);
     const bool fast = g.a_vec && g.b_vec && (a_cols % 4 == 0) && (b_cols % 4 == 0) && ab < 0xFFFF0000L && bb < 0xFFFF0000L;
     g.a_bytes = (unsigned)ab; g.b_bytes = (unsigned)bb;
+    g.n_major = bb > ab;        // share the larger operand's panel between neighbouring workgroups
     if (fast)
         hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, 1, 2, 4, 1, EPI, true>), grid, block, 0, stream, g);
     else
@@ -148,7 +149,7 @@ int reduce_slabs_internal(const float* slabs, long stride, int nslabs, float* ou
 // L).  Workgroups are resident 3 per CU (register budget of the 128x64 tile), so a launch runs in
 // ceil(tiles*s / slots) rounds of ceil(ktiles/s) k-tiles each; pick the s that minimises
 // rounds x (k-tiles per workgroup + fixed per-workgroup cost) + the slab-reduction cost.
-int choose_splits(int tiles, int ktiles, int max_splits) {
+int choose_splits(int tiles, int ktiles, int max_splits, bool prefer_xcd_multiple) {
     static int slots = 0;
     if (!slots) {
         int dev = 0, cus = 256;
@@ -173,7 +174,8 @@ int choose_splits(int tiles, int ktiles, int max_splits) {
         const long rest = blocks - full * slots;
         const int share = (int)((rest + per_cu - 1) / per_cu);          // 0..3 workgroups per CU in the last round
         const double passes = 3.0 * full + (share ? share / eff[share] : 0.0);
-        const double cost = passes * (per + 3.5) + 0.003 * tiles * s;   // + slab reduction
+        double cost = passes * (per + 3.5) + 0.003 * tiles * s;         // + slab reduction
+        if (prefer_xcd_multiple && s % 8 == 0) cost *= 0.93;             // one reduction slice per XCD: operands fetched once
         if (cost < best) { best = cost; best_s = s; }
     }
     return best_s;

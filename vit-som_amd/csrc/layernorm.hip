@@ -107,8 +107,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
 }
 
 static int ln_bwd_blocks(int rows) {
-    int b = cdiv(rows, 64);          // >= 16 rows per wave
-    if (b > 512) b = 512;
+    int b = cdiv(rows, 16);          // ~4 rows per wave: 8 workgroups per CU keep enough loads in flight
+    if (b > 2048) b = 2048;
     if (b < 1) b = 1;
     return b;
 }

@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void bmu_finalize_kernel(const float* __restri
 }
 
 static int bmu_splits(int B, int K, int L) {
-    return choose_splits(cdiv(B, 128) * cdiv(K, 64), cdiv(L, 32), 32);
+    return choose_splits(cdiv(B, 128) * cdiv(K, 64), cdiv(L, 32), 32, true);
 }
 
 // ------------------------------------------------------------------ neighbourhood / loss / coefficients
