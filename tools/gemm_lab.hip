@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <vector>
+#include <math.h>
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -92,6 +93,91 @@ void run(const char* tag, const float* A, const float* B, float* C, int M, int N
     for (int r = 0; r < 5; ++r) { hipEventRecord(e0); for (int i = 0; i < 5; ++i) go(); hipEventRecord(e1); hipEventSynchronize(e1); float ms; hipEventElapsedTime(&ms, e0, e1); if (ms / 5 < best) best = ms / 5; }
     printf("%-28s tile %dx%d waves %dx%d mode %2d occ %d: %7.1f us  %6.1f TF\n", tag, BM, BN, WAVES_M, WAVES_N, MODE, OCC, best * 1e3, 2.0 * M * N * K / best / 1e9);
 }
+
+// ---- variant: direct-to-LDS loads (global_load_lds dwordx4), double-buffered, XOR-swizzled unpadded image --------
+// LDS image per operand tile: [rows][32 floats]; 16-B chunk position p of row r holds global chunk p ^ ((r>>1)&7).
+template <int WM, int WN, int WAVES_M, int WAVES_N, int OCC>
+__global__ __launch_bounds__(WAVES_M * WAVES_N * 64, OCC) void lab_glds(const float* __restrict__ A, const float* __restrict__ B,
+                                                                   float* __restrict__ C, int M, int N, int K) {
+    constexpr int NW = WAVES_M * WAVES_N;
+    constexpr int BM = WAVES_M * WM * 32, BN = WAVES_N * WN * 32;
+    constexpr int TILE = (BM + BN) * 32;                  // floats per stage
+    __shared__ __attribute__((aligned(16))) float lds[2 * TILE];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, r = lane & 31, h = lane >> 5;
+    const int wm0 = (wave / WAVES_N) * WM * 32, wn0 = (wave % WAVES_N) * WN * 32;
+    const int tiles_n = N / BN;
+    const int bm0 = (blockIdx.x / tiles_n) * BM, bn0 = (blockIdx.x % tiles_n) * BN;
+    f32x16 acc[WM][WN];
+    for (int i = 0; i < WM; ++i) for (int j = 0; j < WN; ++j) for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+    // each wave-instruction fills 8 rows (1 KiB): lane -> (row_in_8 = lane>>3, position p = lane&7)
+    const int lrow = lane >> 3, lp = lane & 7;
+    auto stage = [&](int buf, int k0) {
+        float* As = lds + buf * TILE; float* Bs = As + BM * 32;
+#pragma unroll
+        for (int q = 0; q < BM / 8 / NW; ++q) {
+            const int row = (q * NW + wave) * 8 + lrow;               // row within the A tile
+            const int c = lp ^ ((row >> 1) & 7);
+            const float* src = A + (long)(bm0 + row) * K + k0 + 4 * c;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(As + (q * NW + wave) * 256), 16, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < BN / 8 / NW; ++q) {
+            const int row = (q * NW + wave) * 8 + lrow;
+            const int c = lp ^ ((row >> 1) & 7);
+            const float* src = B + (long)(bn0 + row) * K + k0 + 4 * c;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(Bs + (q * NW + wave) * 256), 16, 0, 0);
+        }
+    };
+    stage(0, 0);
+    __syncthreads();
+    const int nk = K / 32;
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) stage((kt + 1) & 1, (kt + 1) * 32);
+        const float* As = lds + (kt & 1) * TILE; const float* Bs = As + BM * 32;
+#pragma unroll
+        for (int kb = 0; kb < 32; kb += 8) {
+            f32x4 a[WM], b[WN];
+#pragma unroll
+            for (int i = 0; i < WM; ++i) { const int row = wm0 + i * 32 + r; a[i] = *(const f32x4*)(As + row * 32 + 4 * ((kb / 4 + h) ^ ((row >> 1) & 7))); }
+#pragma unroll
+            for (int j = 0; j < WN; ++j) { const int row = wn0 + j * 32 + r; b[j] = *(const f32x4*)(Bs + row * 32 + 4 * ((kb / 4 + h) ^ ((row >> 1) & 7))); }
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int i = 0; i < WM; ++i)
+#pragma unroll
+                    for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int m = bm0 + wm0 + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * h, n = bn0 + wn0 + j * 32 + r;
+                C[(long)m * N + n] = acc[i][j][v];
+            }
+}
+template <int WM, int WN, int WAVES_M, int WAVES_N, int OCC>
+void run_glds(const char* tag, const float* A, const float* B, float* C, float* Cref, int M, int N, int K) {
+    constexpr int BM = WAVES_M * WM * 32, BN = WAVES_N * WN * 32;
+    dim3 grid((M / BM) * (N / BN));
+    auto go = [&]() { hipLaunchKernelGGL((lab_glds<WM, WN, WAVES_M, WAVES_N, OCC>), grid, dim3(WAVES_M * WAVES_N * 64), 0, 0, A, B, C, M, N, K); };
+    go(); hipDeviceSynchronize();
+    // check against the register-staged kernel's output
+    std::vector<float> x(1 << 16), y(1 << 16);
+    hipMemcpy(x.data(), C + 12345, x.size() * 4, hipMemcpyDeviceToHost); hipMemcpy(y.data(), Cref + 12345, y.size() * 4, hipMemcpyDeviceToHost);
+    double md = 0; for (size_t i = 0; i < x.size(); ++i) md = fmax(md, fabs((double)x[i] - y[i]));
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    float best = 1e9;
+    for (int r = 0; r < 5; ++r) { hipEventRecord(e0); for (int i = 0; i < 5; ++i) go(); hipEventRecord(e1); hipEventSynchronize(e1); float ms; hipEventElapsedTime(&ms, e0, e1); if (ms / 5 < best) best = ms / 5; }
+    printf("%-28s tile %dx%d waves %dx%d occ %d: %7.1f us  %6.1f TF   (max |diff| vs reg-staged %.3g)\n", tag, BM, BN, WAVES_M, WAVES_N, OCC, best * 1e3, 2.0 * M * N * K / best / 1e9, md);
+}
+
 int main() {
     const int M = 33280, N = 576, K = 192;
     float *A, *B, *C; hipMalloc(&A, (size_t)M * K * 4); hipMalloc(&B, (size_t)N * K * 4); hipMalloc(&C, (size_t)M * N * 4);
@@ -103,6 +189,12 @@ int main() {
     run<1, 2, 4, 1, 7, 1>("+global loads", A, B, C, M, N, K);
     run<1, 2, 4, 1, 15, 1>("full", A, B, C, M, N, K);
     run<1, 2, 4, 1, 8, 1>("mfma+epilogue", A, B, C, M, N, K);
+    float* C2; hipMalloc(&C2, (size_t)M * N * 4);
+    run<1, 2, 4, 1, 15, 1>("full (reference out)", A, B, C2, M, N, K);
+    run_glds<1, 2, 4, 1, 1>("glds dbuf", A, B, C, C2, M, N, K);
+    run_glds<1, 2, 4, 1, 3>("glds dbuf", A, B, C, C2, M, N, K);
+    run_glds<1, 2, 4, 1, 4>("glds dbuf", A, B, C, C2, M, N, K);
+    run_glds<2, 2, 2, 2, 2>("glds dbuf 128x128", A, B, C, C2, M, N, K);
     run<1, 2, 4, 1, 15, 2>("full occ2", A, B, C, M, N, K);
     run<1, 2, 4, 1, 15, 3>("full occ3", A, B, C, M, N, K);
     run<1, 2, 4, 1, 15, 4>("full occ4", A, B, C, M, N, K);

@@ -177,13 +177,13 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const float* __restrict__
             }
             cmax = group_max(cmax);
             const float mnew = fmaxf(m, cmax);
-            const float alpha = expf(m - mnew);
+            const float alpha = __expf(m - mnew);
             float psum = 0.f;
 #pragma unroll
             for (int tt = 0; tt < 4; ++tt)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float p = expf(s[tt][e] - mnew);
+                    const float p = __expf(s[tt][e] - mnew);
                     s[tt][e] = p;
                     psum += p;
                 }
@@ -253,7 +253,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const float* __restric
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int key = 16 * t + 4 * qp + e;
-                const float p = (key < N && qok) ? expf(s[e] * scale - lq) : 0.f;
+                const float p = (key < N && qok) ? __expf(s[e] * scale - lq) : 0.f;
                 ds[e] = p * (dp[e] - D) * scale;
             }
             accum_tile<HDP>(dq, Ks, t, r, qp, ds);
@@ -309,7 +309,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const float* __restri
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int query = 16 * t + 4 * qp + e;
-                p[e] = (query < N && kok) ? expf(s[e] * scale - Ls[query]) : 0.f;
+                p[e] = (query < N && kok) ? __expf(s[e] * scale - Ls[query]) : 0.f;
                 ds[e] = p[e] * (dp[e] - Es[query]) * scale;
             }
             accum_tile<HDP>(dv, Ds, t, r, qp, p);

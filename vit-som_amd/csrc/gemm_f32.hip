@@ -80,7 +80,7 @@ int launch_gemm(bool a_kc, bool b_kc, int epi, GemmP g, int splits, hipStream_t 
 // A workgroup owns 256 consecutive columns (64 lanes x float4); its WAVES waves stride over the
 // slabs with four independent accumulators each (loads in flight instead of one dependent chain)
 // and are combined through LDS in wave order: the summation order is fixed -> bitwise reproducible.
-template <int WAVES>
+template <int WAVES, int VEC>
 __global__ __launch_bounds__(WAVES * 64) void reduce_slabs_kernel(const float* __restrict__ slabs, long stride,
                                                                   int nslabs, float* __restrict__ out1, long n1,
                                                                   float* __restrict__ out2, long off2, long n2,
@@ -88,20 +88,27 @@ __global__ __launch_bounds__(WAVES * 64) void reduce_slabs_kernel(const float* _
     __shared__ __attribute__((aligned(16))) f32x4 sh[WAVES][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool seg2 = (int)blockIdx.x >= nb1;
-    const long col = ((long)(seg2 ? blockIdx.x - nb1 : blockIdx.x) * 64 + lane) * 4;
+    const long col = ((long)(seg2 ? blockIdx.x - nb1 : blockIdx.x) * 64 + lane) * VEC;
     const long n = seg2 ? n2 : n1;
     const float* src = slabs + (seg2 ? off2 : 0) + col;
     f32x4 acc[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (col < n) {
-        if (vec && col + 3 < n) {
+        if (VEC == 4 && vec && col + 3 < n) {
             int s = wave;
             for (; s + 3 * WAVES < nslabs; s += 4 * WAVES) {
 #pragma unroll
                 for (int u = 0; u < 4; ++u) acc[u] += *reinterpret_cast<const f32x4*>(src + (long)(s + u * WAVES) * stride);
             }
             for (; s < nslabs; s += WAVES) acc[0] += *reinterpret_cast<const f32x4*>(src + (long)s * stride);
+        } else if (VEC == 1) {                           // narrow outputs (LayerNorm / bias): one column per lane
+            int s = wave;
+            for (; s + 3 * WAVES < nslabs; s += 4 * WAVES) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc[u][0] += src[(long)(s + u * WAVES) * stride];
+            }
+            for (; s < nslabs; s += WAVES) acc[0][0] += src[(long)s * stride];
         } else {
             for (int s = wave; s < nslabs; s += WAVES)
 #pragma unroll
@@ -116,7 +123,9 @@ __global__ __launch_bounds__(WAVES * 64) void reduce_slabs_kernel(const float* _
 #pragma unroll
         for (int w = 1; w < WAVES; ++w) t += sh[w][lane];
         float* dst = (seg2 ? out2 : out1) + col;
-        if (col + 3 < n && (reinterpret_cast<uintptr_t>(dst) & 15u) == 0) {
+        if (VEC == 1) {
+            dst[0] = t[0];
+        } else if (col + 3 < n && (reinterpret_cast<uintptr_t>(dst) & 15u) == 0) {
             *reinterpret_cast<f32x4*>(dst) = t;
         } else {
 #pragma unroll
@@ -131,13 +140,15 @@ int reduce_slabs2_internal(const float* slabs, long stride, int nslabs, float* o
     if (n1 <= 0 && n2 <= 0) return VSOM_OK;
     if (!out2) n2 = 0;
     const int vec = aligned16(slabs) && (stride % 4 == 0) && (off2 % 4 == 0);
-    const int nb1 = cdiv(n1, 256), nb2 = n2 > 0 ? cdiv(n2, 256) : 0;
-    if (n1 + n2 <= 8192 && nslabs >= 32)
-        hipLaunchKernelGGL(reduce_slabs_kernel<16>, dim3(nb1 + nb2), dim3(1024), 0, stream, slabs, stride, nslabs, out1, n1,
+    if (n1 + n2 <= 4096 && nslabs >= 32) {
+        const int nb1 = cdiv(n1, 64), nb2 = n2 > 0 ? cdiv(n2, 64) : 0;
+        hipLaunchKernelGGL((reduce_slabs_kernel<16, 1>), dim3(nb1 + nb2), dim3(1024), 0, stream, slabs, stride, nslabs, out1,
+                           n1, out2, off2, n2, nb1, vec);
+    } else {
+        const int nb1 = cdiv(n1, 256), nb2 = n2 > 0 ? cdiv(n2, 256) : 0;
+        hipLaunchKernelGGL((reduce_slabs_kernel<4, 4>), dim3(nb1 + nb2), dim3(256), 0, stream, slabs, stride, nslabs, out1, n1,
                            out2, off2, n2, nb1, vec);
-    else
-        hipLaunchKernelGGL(reduce_slabs_kernel<4>, dim3(nb1 + nb2), dim3(256), 0, stream, slabs, stride, nslabs, out1, n1,
-                           out2, off2, n2, nb1, vec);
+    }
     VSOM_LAUNCH_CHECK("reduce_slabs_kernel");
 }
 
