@@ -34,6 +34,9 @@ typedef struct ihipStream_t* vsom_stream_t; /* == hipStream_t */
 
 #define VSOM_VERSION 100
 
+#define VSOM_DIST_COSINE 0
+#define VSOM_DIST_EUCLIDEAN 1
+
 int vsom_version(void);
 const char* vsom_last_error_string(void);
 
@@ -107,6 +110,8 @@ int vsom_attention_bwd(const float* qkv, const float* out, const float* dout, co
 /* inv_norm[r] = 1 / max(||X[r,:]||_2, eps)   -- F.normalize(p=2, eps=1e-12), som_layer.py:120-121 */
 int vsom_row_inv_norm(const float* X, long ldx, int rows, int cols, float eps, float* inv_norm,
                       vsom_stream_t stream);
+/* sqnorm[r] = ||X[r,:]||_2^2  (for the euclidean distance) */
+int vsom_row_sqnorm(const float* X, long ldx, int rows, int cols, float* sqnorm, vsom_stream_t stream);
 /* Best-matching-unit search, cosine: dist[B,K] = 1 - (X/|X|)(W/|W|)^T ; bmu[b] = first argmin_k
  * -- SOMLayer.compute_distances + forward, som_layer.py:83-89,119-122.  X [B,L] (row stride ldx:
  * the patch tokens of image b are contiguous), W [K,L] dense.  dist may be NULL. */
@@ -121,18 +126,25 @@ int vsom_bmu_cosine_dots(const float* X, long ldx, const float* W, int B, int K,
                          size_t ws_bytes, vsom_stream_t stream);
 int vsom_bmu_cosine_finalize(const void* ws, size_t ws_bytes, const float* inv_nx, const float* inv_nw,
                              float* dist, int64_t* bmu, int B, int K, int L, vsom_stream_t stream);
+/* Best-matching-unit search, euclidean: dist = torch.cdist(X, W, p=2) in its matmul form
+ * sqrt(clamp_min(|x|^2 + |w|^2 - 2 x.w, 1e-30)) -- som_layer.py:117-118; same workspace as cosine. */
+int vsom_bmu_euclid_fwd(const float* X, long ldx, const float* W, const float* sq_x, const float* sq_w,
+                        float* dist, int64_t* bmu, int B, int K, int L, void* ws, size_t ws_bytes,
+                        vsom_stream_t stream);
 /* Neighbourhood weights + SOM loss + backward coefficients in one pass over [B,K]:
  *   h_ik = exp(-||g_k - g_bmu(i)||^2 / (2 T^2))              compute_weights, som_layer.py:144-152
  *   loss_sum[0] = sum_ik h_ik d_ik   (caller divides by B*K)  som_loss, som_layer.py:137-142
  *   (all loss sums are two-stage fixed-order reductions: bitwise reproducible)
  *   coef[i,k] = -c * h_ik * inv_nx[i] * inv_nw[k],  c = grad_scale
  *   row_dot[i] = c * inv_nx[i]^2 * sum_k h_ik (1 - d_ik);  col_dot[k] likewise over i
+ * (distance = VSOM_DIST_EUCLIDEAN: coef = -c h/d, row_dot = c sum_k h/d, col_dot = c sum_i h/d, the
+ *  coefficients of d|x-w|; inv_nx / inv_nw are then unused and vsom_som_bwd applies unchanged)
  * h may be NULL; coef/row_dot/col_dot may all be NULL (forward only).  grid [K,2] float. */
 size_t vsom_som_neigh_workspace_bytes(int B, int K);
 int vsom_som_neigh_loss(const float* dist, const int64_t* bmu, const float* grid, float T,
                         const float* inv_nx, const float* inv_nw, float grad_scale, float* h,
                         float* loss_sum, float* coef, float* row_dot, float* col_dot, int B, int K,
-                        void* ws, size_t ws_bytes, vsom_stream_t stream);
+                        int distance, void* ws, size_t ws_bytes, vsom_stream_t stream);
 /* Prototype gradient ("per-BMU neighbourhood accumulator") and input gradient of
  * gamma_t * mean(h * d) through both F.normalize calls:
  *   gW[K,L]  = coef^T X + col_dot[k] * W[k,:]

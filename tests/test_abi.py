@@ -44,6 +44,7 @@ def test_argument_validation_without_gpu():
     assert lib.vsom_layernorm_fwd(16, 16, 16, 16, 16, 16, 4, 2048, 1e-6, None) == -3               # cols > 1024
     assert lib.vsom_attention_fwd(16, 16, 16, 1, 17, 2, 24, None) == -3                             # head dim 24
     assert lib.vsom_bmu_cosine_fwd(16, 8, 16, 16, 16, None, 16, 2, 3, 8, None, 0, None) == -4       # no workspace
+    assert lib.vsom_som_neigh_loss(16, 16, 16, 1.0, None, None, 0.0, None, 16, None, None, None, 2, 3, 7, 16, 64, None) == -3   # distance 7
     # workspace queries are pure host arithmetic
     assert lib.vsom_linear_bwd_weight_workspace_bytes(33280, 576, 192) > 576 * 192 * 4
     assert lib.vsom_bmu_cosine_workspace_bytes(512, 1600, 12288) >= 512 * 1600 * 4

@@ -108,7 +108,8 @@ def test_compute_has_no_cpu_path():
     with pytest.raises(NotImplementedError):
         import vit_som_amd
         _, cfg = load_golden("ref_hexa_euclid_tiny")
-        vit_som_amd.ViTSOM(cfg, device="cpu")       # euclidean distance: no HIP kernel yet
+        cfg["hyperparameters"]["som"]["distance_fcn"] = "manhattan"
+        vit_som_amd.ViTSOM(cfg, device="cpu")       # manhattan distance (DESOM configs): no HIP kernel yet
 
 
 def test_patchify_roundtrip():

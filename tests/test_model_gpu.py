@@ -8,7 +8,7 @@ import torch
 from helpers import REF_CASES, golden_params, load_golden, rel_err
 
 pytestmark = pytest.mark.gpu
-COSINE_CASES = [c for c in REF_CASES if "euclid" not in c]
+COSINE_CASES = REF_CASES      # cosine/square, and the euclidean + hexa variant
 DEV = "cuda"
 
 

@@ -350,3 +350,33 @@ def test_errors_are_loud(ops):
         ops.layernorm_fwd(x, x[0], x[0], torch.empty_like(x), torch.empty(4, device=DEV), torch.empty(4, device=DEV))
     with pytest.raises(ValueError):
         ops.linear_fwd(torch.empty(4, 4), torch.empty(4, 4), None, torch.empty(4, 4))   # CPU tensors
+
+
+@pytest.mark.parametrize("B,K,L,map_size,topo", [(64, 100, 3136, (10, 10), "square"), (33, 12, 48, (4, 3), "hexa")])
+def test_som_euclidean_fwd_and_bwd(ops, O, B, K, L, map_size, topo):
+    """euclidean distance variant (torch.cdist p=2) + its SOM-loss gradients."""
+    x = rnd(B, L, seed=1)
+    W = torch.rand(K, L, generator=torch.Generator().manual_seed(2))
+    grid = O.grid_positions(map_size, topo)
+    T, gam = 2.3, 0.5
+    xl, Wl = x.clone().double().requires_grad_(True), W.clone().double().requires_grad_(True)
+    d_ref = torch.cdist(xl, Wl, p=2)
+    bmu_ref = d_ref.argmin(1)
+    loss_ref = O.som_loss(O.neighbourhood(bmu_ref, grid.double(), T), d_ref)
+    (gam * loss_ref).backward()
+    xd, Wd = dev(x), dev(W)
+    sx, sw = torch.empty(B, device=DEV), torch.empty(K, device=DEV)
+    ops.row_sqnorm(xd, sx); ops.row_sqnorm(Wd, sw)
+    assert torch.allclose(sx.cpu(), (x * x).sum(1), rtol=2e-6)
+    dist, bmu = torch.empty(B, K, device=DEV), torch.empty(B, dtype=torch.int64, device=DEV)
+    ops.bmu_euclid_fwd(xd, Wd, sx, sw, dist, bmu)
+    assert torch.allclose(dist.cpu().double(), d_ref.detach(), atol=1e-4, rtol=1e-6)     # matmul form: |x|^2-scale cancellation
+    assert torch.equal(bmu.cpu(), dist.cpu().argmin(1)) and torch.equal(bmu.cpu(), bmu_ref)
+    loss = torch.zeros(1, device=DEV)
+    coef = torch.empty(B, K, device=DEV); rd = torch.empty(B, device=DEV); cd = torch.empty(K, device=DEV)
+    ops.som_neigh_loss(dist, bmu, dev(grid), T, loss, grad_scale=gam / (B * K), coef=coef, row_dot=rd, col_dot=cd,
+                       distance=ops.DIST_EUCLIDEAN)
+    assert abs(float(loss) / (B * K) - float(loss_ref.detach())) < 1e-5 * float(loss_ref.detach())
+    gW, gX = torch.empty(K, L, device=DEV), torch.zeros(B, L, device=DEV)
+    ops.som_bwd(xd, Wd, coef, rd, cd, gW, gX, accumulate_gx=False)
+    assert rel_err(gW.cpu(), Wl.grad) < 5e-5 and rel_err(gX.cpu(), xl.grad) < 5e-5

@@ -38,6 +38,9 @@ SIGNATURES = {
     "vsom_attention_fwd": (C.c_int, [c_fp, c_fp, c_fp, C.c_int, C.c_int, C.c_int, C.c_int, c_stream]),
     "vsom_attention_bwd": (C.c_int, [c_fp] * 6 + [C.c_int] * 4 + [c_stream]),
     "vsom_row_inv_norm": (C.c_int, [c_fp, C.c_long, C.c_int, C.c_int, C.c_float, c_fp, c_stream]),
+    "vsom_row_sqnorm": (C.c_int, [c_fp, C.c_long, C.c_int, C.c_int, c_fp, c_stream]),
+    "vsom_bmu_euclid_fwd": (C.c_int, [c_fp, C.c_long, c_fp, c_fp, c_fp, c_fp, c_fp, C.c_int, C.c_int, C.c_int, c_fp,
+                                      C.c_size_t, c_stream]),
     "vsom_bmu_cosine_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "vsom_bmu_cosine_fwd": (C.c_int, [c_fp, C.c_long, c_fp, c_fp, c_fp, c_fp, c_fp, C.c_int, C.c_int, C.c_int, c_fp,
                                       C.c_size_t, c_stream]),
@@ -45,7 +48,7 @@ SIGNATURES = {
     "vsom_bmu_cosine_finalize": (C.c_int, [c_fp, C.c_size_t, c_fp, c_fp, c_fp, c_fp, C.c_int, C.c_int, C.c_int, c_stream]),
     "vsom_som_neigh_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "vsom_som_neigh_loss": (C.c_int, [c_fp, c_fp, c_fp, C.c_float, c_fp, c_fp, C.c_float, c_fp, c_fp, c_fp, c_fp,
-                                      c_fp, C.c_int, C.c_int, c_fp, C.c_size_t, c_stream]),
+                                      c_fp, C.c_int, C.c_int, C.c_int, c_fp, C.c_size_t, c_stream]),
     "vsom_som_bwd": (C.c_int, [c_fp, C.c_long, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, C.c_long, C.c_int, C.c_int,
                                C.c_int, C.c_int, c_stream]),
     "vsom_l1_unpatchify_workspace_bytes": (C.c_size_t, [C.c_int] * 4),

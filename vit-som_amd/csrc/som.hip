@@ -8,7 +8,7 @@ namespace vsom {
 // one wave per row, 16-byte loads; rows are 12-49k floats at the BASELINE configs
 __global__ __launch_bounds__(256) void row_inv_norm_kernel(const float* __restrict__ X, long ldx, int rows,
                                                            int cols, float eps, float* __restrict__ out,
-                                                           int vec) {
+                                                           int vec, int squared) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -25,7 +25,7 @@ __global__ __launch_bounds__(256) void row_inv_norm_kernel(const float* __restri
         for (int i = lane; i < cols; i += 64) s = fmaf(x[i], x[i], s);
     }
     s = wave_sum(s);
-    if (lane == 0) out[row] = 1.0f / fmaxf(sqrtf(s), eps);
+    if (lane == 0) out[row] = squared ? s : 1.0f / fmaxf(sqrtf(s), eps);
 }
 
 // ------------------------------------------------------------------ BMU finalize
@@ -36,15 +36,16 @@ __global__ __launch_bounds__(256) void bmu_finalize_kernel(const float* __restri
                                                            int nslabs, const float* __restrict__ inv_nx,
                                                            const float* __restrict__ inv_nw,
                                                            float* __restrict__ dist, int64_t* __restrict__ bmu,
-                                                           int K) {
+                                                           int K, int euclid) {
     const int i = blockIdx.x;
-    const float rx = inv_nx[i];
+    const float rx = inv_nx[i];          // cosine: 1/|x_i| ; euclidean: |x_i|^2
     float best = INFINITY;
     int bidx = 0x7fffffff;
     for (int k = threadIdx.x; k < K; k += 256) {
         float dot = 0.f;
         for (int s = 0; s < nslabs; ++s) dot += slab[(long)s * slab_stride + (long)i * K + k];
-        const float d = 1.0f - dot * rx * inv_nw[k];
+        // euclidean: torch.cdist's matmul form  sqrt(clamp_min(|x|^2 + |w|^2 - 2 x.w, 1e-30))
+        const float d = euclid ? sqrtf(fmaxf(fmaf(-2.0f, dot, rx + inv_nw[k]), 1e-30f)) : 1.0f - dot * rx * inv_nw[k];
         if (dist) dist[(long)i * K + k] = d;
         if (d < best || (d == best && k < bidx)) { best = d; bidx = k; }
     }
@@ -79,20 +80,26 @@ __global__ __launch_bounds__(256) void som_neigh_row_kernel(const float* __restr
                                                             const float* __restrict__ inv_nw, float c,
                                                             float* __restrict__ h_out, float* __restrict__ coef,
                                                             float* __restrict__ row_dot,
-                                                            float* __restrict__ loss_part, int K) {
+                                                            float* __restrict__ loss_part, int K, int euclid) {
     const int i = blockIdx.x;
     const int64_t b = bmu[i];
     const float by = grid[2 * b], bx = grid[2 * b + 1];
-    const float rx = inv_nx ? inv_nx[i] : 0.f;
+    const float rx = (inv_nx && !euclid) ? inv_nx[i] : 0.f;
     float lsum = 0.f, dsum = 0.f;
     for (int k = threadIdx.x; k < K; k += 256) {
         const float dy = grid[2 * k] - by, dx = grid[2 * k + 1] - bx;
         const float h = expf(-(dy * dy + dx * dx) * inv_2T2);
         const float d = dist[(long)i * K + k];
         if (h_out) h_out[(long)i * K + k] = h;
-        if (coef) coef[(long)i * K + k] = -c * h * rx * inv_nw[k];
+        if (euclid) {
+            const float hd = (d > 0.f) ? h / d : 0.f;           // d|x-w|/dx = (x-w)/d ; torch gives 0 at d == 0
+            if (coef) coef[(long)i * K + k] = -c * hd;
+            dsum += hd;
+        } else {
+            if (coef) coef[(long)i * K + k] = -c * h * rx * inv_nw[k];
+            dsum = fmaf(h, 1.0f - d, dsum);
+        }
         lsum = fmaf(h, d, lsum);
-        dsum = fmaf(h, 1.0f - d, dsum);
     }
     lsum = wave_sum(lsum);
     dsum = wave_sum(dsum);
@@ -101,7 +108,7 @@ __global__ __launch_bounds__(256) void som_neigh_row_kernel(const float* __restr
     __syncthreads();
     if (threadIdx.x == 0) {
         loss_part[i] = (s1[0] + s1[1]) + (s1[2] + s1[3]);
-        if (row_dot) row_dot[i] = c * rx * rx * ((s2[0] + s2[1]) + (s2[2] + s2[3]));
+        if (row_dot) row_dot[i] = c * (euclid ? 1.0f : rx * rx) * ((s2[0] + s2[1]) + (s2[2] + s2[3]));
     }
 }
 // thread per prototype column k, fixed-order loop over the B sample rows
@@ -109,7 +116,7 @@ __global__ __launch_bounds__(256) void som_neigh_col_kernel(const float* __restr
                                                             const int64_t* __restrict__ bmu,
                                                             const float* __restrict__ grid, float inv_2T2,
                                                             const float* __restrict__ inv_nw, float c,
-                                                            float* __restrict__ col_dot, int B, int K) {
+                                                            float* __restrict__ col_dot, int B, int K, int euclid) {
     const int k = blockIdx.x * 256 + threadIdx.x;
     if (k >= K) return;
     const float gy = grid[2 * k], gx = grid[2 * k + 1];
@@ -118,9 +125,10 @@ __global__ __launch_bounds__(256) void som_neigh_col_kernel(const float* __restr
         const int64_t b = bmu[i];
         const float dy = gy - grid[2 * b], dx = gx - grid[2 * b + 1];
         const float h = expf(-(dy * dy + dx * dx) * inv_2T2);
-        s = fmaf(h, 1.0f - dist[(long)i * K + k], s);
+        const float d = dist[(long)i * K + k];
+        s += euclid ? ((d > 0.f) ? h / d : 0.f) : h * (1.0f - d);
     }
-    const float rw = inv_nw[k];
+    const float rw = euclid ? 1.0f : inv_nw[k];
     col_dot[k] = c * rw * rw * s;
 }
 // deterministic sum of n partials into out[0] (single workgroup)
@@ -151,7 +159,15 @@ int vsom_row_inv_norm(const float* X, long ldx, int rows, int cols, float eps, f
     VSOM_REQUIRE(X && inv_norm && rows > 0 && cols > 0 && ldx >= cols, VSOM_EINVAL, "row_inv_norm: bad arguments");
     const int vec = aligned16(X) && (ldx % 4 == 0);
     hipLaunchKernelGGL(row_inv_norm_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, stream, X, ldx, rows, cols, eps,
-                       inv_norm, vec);
+                       inv_norm, vec, 0);
+    VSOM_LAUNCH_CHECK("row_inv_norm_kernel");
+}
+
+int vsom_row_sqnorm(const float* X, long ldx, int rows, int cols, float* sqnorm, vsom_stream_t stream) {
+    VSOM_REQUIRE(X && sqnorm && rows > 0 && cols > 0 && ldx >= cols, VSOM_EINVAL, "row_sqnorm: bad arguments");
+    const int vec = aligned16(X) && (ldx % 4 == 0);
+    hipLaunchKernelGGL(row_inv_norm_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, stream, X, ldx, rows, cols, 0.f, sqnorm,
+                       vec, 1);
     VSOM_LAUNCH_CHECK("row_inv_norm_kernel");
 }
 
@@ -180,7 +196,17 @@ int vsom_bmu_cosine_finalize(const void* ws, size_t ws_bytes, const float* inv_n
     VSOM_REQUIRE(ws && ws_bytes >= vsom_bmu_cosine_workspace_bytes(B, K, L), VSOM_EWORKSPACE,
                  "bmu_cosine_finalize: workspace too small");
     hipLaunchKernelGGL(bmu_finalize_kernel, dim3(B), dim3(256), 0, stream, (const float*)ws, (long)B * K,
-                       bmu_splits(B, K, L), inv_nx, inv_nw, dist, bmu, K);
+                       bmu_splits(B, K, L), inv_nx, inv_nw, dist, bmu, K, 0);
+    VSOM_LAUNCH_CHECK("bmu_finalize_kernel");
+}
+
+int vsom_bmu_euclid_fwd(const float* X, long ldx, const float* W, const float* sq_x, const float* sq_w, float* dist,
+                        int64_t* bmu, int B, int K, int L, void* ws, size_t ws_bytes, vsom_stream_t stream) {
+    VSOM_REQUIRE(sq_x && sq_w && bmu, VSOM_EINVAL, "bmu_euclid_fwd: null pointer");
+    int rc = vsom_bmu_cosine_dots(X, ldx, W, B, K, L, ws, ws_bytes, stream);      // the same X.W^T contraction
+    if (rc) return rc;
+    hipLaunchKernelGGL(bmu_finalize_kernel, dim3(B), dim3(256), 0, stream, (const float*)ws, (long)B * K,
+                       bmu_splits(B, K, L), sq_x, sq_w, dist, bmu, K, 1);
     VSOM_LAUNCH_CHECK("bmu_finalize_kernel");
 }
 
@@ -197,25 +223,28 @@ size_t vsom_som_neigh_workspace_bytes(int B, int K) { (void)K; return B > 0 ? (s
 
 int vsom_som_neigh_loss(const float* dist, const int64_t* bmu, const float* grid, float T, const float* inv_nx,
                         const float* inv_nw, float grad_scale, float* h, float* loss_sum, float* coef,
-                        float* row_dot, float* col_dot, int B, int K, void* ws, size_t ws_bytes,
+                        float* row_dot, float* col_dot, int B, int K, int distance, void* ws, size_t ws_bytes,
                         vsom_stream_t stream) {
+    VSOM_REQUIRE(distance == VSOM_DIST_COSINE || distance == VSOM_DIST_EUCLIDEAN, VSOM_EUNSUPPORTED,
+                 "som_neigh_loss: distance %d not supported", distance);
+    const int euclid = distance == VSOM_DIST_EUCLIDEAN;
     VSOM_REQUIRE(dist && bmu && grid && loss_sum, VSOM_EINVAL, "som_neigh_loss: null pointer");
     VSOM_REQUIRE(B > 0 && K > 0 && T > 0.f, VSOM_EINVAL, "som_neigh_loss: bad shape/temperature");
     VSOM_REQUIRE(ws && ws_bytes >= vsom_som_neigh_workspace_bytes(B, K), VSOM_EWORKSPACE, "som_neigh_loss: workspace too small");
     const bool bwd = coef || row_dot || col_dot;
-    VSOM_REQUIRE(!bwd || (coef && row_dot && col_dot && inv_nx && inv_nw), VSOM_EINVAL,
-                 "som_neigh_loss: backward outputs need coef, row_dot, col_dot, inv_nx and inv_nw together");
+    VSOM_REQUIRE(!bwd || (coef && row_dot && col_dot && (euclid || (inv_nx && inv_nw))), VSOM_EINVAL,
+                 "som_neigh_loss: backward outputs need coef, row_dot, col_dot (and inv_nx, inv_nw for cosine) together");
     const float inv_2T2 = (float)(1.0 / (2.0 * (double)T * (double)T));
     float* part = static_cast<float*>(ws);
     hipLaunchKernelGGL(som_neigh_row_kernel, dim3(B), dim3(256), 0, stream, dist, bmu, grid, inv_2T2, inv_nx, inv_nw,
-                       grad_scale, h, coef, row_dot, part, K);
+                       grad_scale, h, coef, row_dot, part, K, euclid);
     int rc = hip_status(hipGetLastError(), "som_neigh_row_kernel");
     if (rc) return rc;
     rc = sum_partials(part, B, loss_sum, stream);
     if (rc) return rc;
     if (bwd) {
         hipLaunchKernelGGL(som_neigh_col_kernel, dim3(cdiv(K, 256)), dim3(256), 0, stream, dist, bmu, grid, inv_2T2,
-                           inv_nw, grad_scale, col_dot, B, K);
+                           inv_nw, grad_scale, col_dot, B, K, euclid);
         rc = hip_status(hipGetLastError(), "som_neigh_col_kernel");
     }
     return rc;

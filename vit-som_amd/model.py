@@ -380,16 +380,21 @@ class SOMLayer(_Base):
         self.n_prototypes = int(np.prod(self.map_size))
         if self.model_arch != "vit_som":
             raise NotImplementedError("only model_arch == 'vit_som' is on the accelerated path")
-        if self.distance_fcn != "cosine":
+        if self.distance_fcn not in ("cosine", "euclidean"):
             raise NotImplementedError(
-                f"distance_fcn={self.distance_fcn!r}: only 'cosine' (every shipped vit_som config) has a HIP kernel yet")
+                f"distance_fcn={self.distance_fcn!r}: 'cosine' (every shipped vit_som config) and 'euclidean' have HIP "
+                "kernels; 'manhattan' (DESOM configs) does not yet")
+        self._dist_mode = ops.DIST_COSINE if self.distance_fcn == "cosine" else ops.DIST_EUCLIDEAN
         self.use_reduced = som_hp["use_reduced"]
         latent_dim = vit_hp["emb_dim"]
         if not self.use_reduced:
             latent_dim *= (data_hp["input_size"] // vit_hp["patch_size"]) ** 2
         self.latent_dim = latent_dim
         self.current_temperature = self.Tmax
-        self.prototypes = nn.Parameter(torch.nn.functional.normalize(torch.rand(self.n_prototypes, latent_dim), p=2, dim=1))
+        proto = torch.rand(self.n_prototypes, latent_dim)                      # som_layer.py:44-56
+        if self.distance_fcn == "cosine":
+            proto = torch.nn.functional.normalize(proto, p=2, dim=1)
+        self.prototypes = nn.Parameter(proto)
         self.create_grid_positions()
         self._world_size = 1
         self._n_train: Optional[int] = None
@@ -435,9 +440,14 @@ class SOMLayer(_Base):
         return s.dist.clone()
 
     def _distances_into(self, x2d, s: _Acts):
-        ops.row_inv_norm(x2d, s.inx)
-        ops.row_inv_norm(self.prototypes, s.inw)
-        ops.bmu_cosine_fwd(x2d, self.prototypes, s.inx, s.inw, s.dist, s.bmu)
+        if self._dist_mode == ops.DIST_COSINE:
+            ops.row_inv_norm(x2d, s.inx)
+            ops.row_inv_norm(self.prototypes, s.inw)
+            ops.bmu_cosine_fwd(x2d, self.prototypes, s.inx, s.inw, s.dist, s.bmu)
+        else:                                   # euclidean: inx / inw hold the squared norms
+            ops.row_sqnorm(x2d, s.inx)
+            ops.row_sqnorm(self.prototypes, s.inw)
+            ops.bmu_euclid_fwd(x2d, self.prototypes, s.inx, s.inw, s.dist, s.bmu)
 
     @torch.no_grad()
     def forward(self, x):                                              # som_layer.py:83-89
@@ -476,7 +486,8 @@ class SOMLayer(_Base):
         h = torch.empty(B, K, dtype=torch.float32, device=dev)
         zero_d = torch.zeros(B, K, dtype=torch.float32, device=dev)
         tmp = torch.empty(1, dtype=torch.float32, device=dev)
-        ops.som_neigh_loss(zero_d, bmu_indices.contiguous(), self.grid_positions, float(self.current_temperature), tmp, h=h)
+        ops.som_neigh_loss(zero_d, bmu_indices.contiguous(), self.grid_positions, float(self.current_temperature), tmp, h=h,
+                           distance=self._dist_mode)
         return h
 
     @torch.no_grad()
@@ -486,7 +497,8 @@ class SOMLayer(_Base):
         B, K = distances.shape
         bmu = torch.argmax(weights, dim=1)        # h_ik is maximal (== 1) exactly at k = bmu(i)  [index plumbing]
         tmp = torch.empty(1, dtype=torch.float32, device=distances.device)
-        ops.som_neigh_loss(distances.contiguous(), bmu, self.grid_positions, float(self.current_temperature), tmp)
+        ops.som_neigh_loss(distances.contiguous(), bmu, self.grid_positions, float(self.current_temperature), tmp,
+                           distance=self._dist_mode)
         return tmp[0] / (B * K)
 
 
@@ -746,9 +758,11 @@ class ViTSOM(_Base):
         c = gamma_t / (B * K)
         if want_grad:
             ops.som_neigh_loss(s.dist, s.bmu, self.som_layer.grid_positions, T, s.loss_sum, inv_nx=s.inx, inv_nw=s.inw,
-                               grad_scale=c, coef=s.coef, row_dot=s.row_dot, col_dot=s.col_dot)
+                               grad_scale=c, coef=s.coef, row_dot=s.row_dot, col_dot=s.col_dot,
+                               distance=self.som_layer._dist_mode)
         else:
-            ops.som_neigh_loss(s.dist, s.bmu, self.som_layer.grid_positions, T, s.loss_sum)
+            ops.som_neigh_loss(s.dist, s.bmu, self.som_layer.grid_positions, T, s.loss_sum,
+                               distance=self.som_layer._dist_mode)
         if self.classification:
             yv = y.view(-1)
             if yv.dtype != torch.int64:

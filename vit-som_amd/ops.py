@@ -182,6 +182,28 @@ def row_inv_norm(x, out, eps=1e-12):
     return out
 
 
+DIST_COSINE, DIST_EUCLIDEAN = 0, 1
+
+
+def row_sqnorm(x, out):
+    rows, cols = x.shape
+    _f32(x, "x")
+    check(lib.vsom_row_sqnorm(ptr(x), _rows(x), rows, cols, ptr(out), stream()), "vsom_row_sqnorm")
+    return out
+
+
+def bmu_euclid_fwd(x, W, sq_x, sq_w, dist: Optional[torch.Tensor], bmu):
+    B, L = x.shape
+    K = W.shape[0]
+    _f32(x, "x"); _f32(W, "W")
+    assert W.is_contiguous() and W.shape[1] == L and bmu.dtype == torch.int64 and (dist is None or dist.is_contiguous())
+    nbytes = lib.vsom_bmu_cosine_workspace_bytes(B, K, L)
+    ws = scratch(nbytes, x.device)
+    check(lib.vsom_bmu_euclid_fwd(ptr(x), _rows(x), ptr(W), ptr(sq_x), ptr(sq_w), ptr(dist), ptr(bmu), B, K, L, ptr(ws),
+                                  ws.numel(), stream()), "vsom_bmu_euclid_fwd")
+    return dist, bmu
+
+
 def bmu_cosine_fwd(x, W, inv_nx, inv_nw, dist: Optional[torch.Tensor], bmu):
     B, L = x.shape
     K = W.shape[0]
@@ -203,13 +225,13 @@ def bmu_cosine_fwd(x, W, inv_nx, inv_nw, dist: Optional[torch.Tensor], bmu):
 
 
 def som_neigh_loss(dist, bmu, grid, T, loss_sum, h=None, inv_nx=None, inv_nw=None, grad_scale=0.0, coef=None,
-                   row_dot=None, col_dot=None):
+                   row_dot=None, col_dot=None, distance=DIST_COSINE):
     B, K = dist.shape
     assert dist.is_contiguous() and grid.is_contiguous() and bmu.dtype == torch.int64
     nbytes = lib.vsom_som_neigh_workspace_bytes(B, K)
     ws = scratch(nbytes, dist.device)
     check(lib.vsom_som_neigh_loss(ptr(dist), ptr(bmu), ptr(grid), float(T), ptr(inv_nx), ptr(inv_nw), float(grad_scale),
-                                  ptr(h), ptr(loss_sum), ptr(coef), ptr(row_dot), ptr(col_dot), B, K, ptr(ws), ws.numel(),
+                                  ptr(h), ptr(loss_sum), ptr(coef), ptr(row_dot), ptr(col_dot), B, K, int(distance), ptr(ws), ws.numel(),
                                   stream()), "vsom_som_neigh_loss")
     return loss_sum
 
