@@ -178,6 +178,15 @@ int vsom_adamw_step(float* p, const float* g, float* m, float* v, const float* w
                     float lr, float beta1, float beta2, float eps, int step, float grad_scale,
                     int adamw, vsom_stream_t stream);
 
+/* ------------------------------------------------------------------ evaluation (tools/evaluation.py) */
+/* table[a[i] * nb + b[i]] += 1 for i < n  (uint64 counts, accumulates: zero it before the first
+ * batch) -- the contingency matrix of calculate_purity (evaluation.py:142-145) and of the
+ * classification metrics.  Entries outside [0,na) x [0,nb) are counted in out_of_range[0]. */
+int vsom_contingency(const int64_t* a, const int64_t* b, long n, int na, int nb,
+                     unsigned long long* table, int* out_of_range, vsom_stream_t stream);
+/* out[r] = first argmax_c X[r,c] -- torch.argmax(cls_logits, dim=1), evaluation.py:119 */
+int vsom_argmax_rows(const float* X, long ldx, int rows, int cols, int64_t* out, vsom_stream_t stream);
+
 /* ------------------------------------------------------------------ small utilities */
 int vsom_fill(float* p, long n, float value, vsom_stream_t stream);
 /* out[j] = sum_s slabs[s*stride + j], j in [0,n) -- fixed summation order */

@@ -59,6 +59,8 @@ SIGNATURES = {
                                         C.c_size_t, c_stream]),
     "vsom_adamw_step": (C.c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, C.c_long, C.c_float, C.c_float, C.c_float, C.c_float,
                                   C.c_int, C.c_float, C.c_int, c_stream]),
+    "vsom_contingency": (C.c_int, [c_fp, c_fp, C.c_long, C.c_int, C.c_int, c_fp, c_fp, c_stream]),
+    "vsom_argmax_rows": (C.c_int, [c_fp, C.c_long, C.c_int, C.c_int, c_fp, c_stream]),
     "vsom_fill": (C.c_int, [c_fp, C.c_long, C.c_float, c_stream]),
     "vsom_reduce_slabs": (C.c_int, [c_fp, C.c_long, C.c_int, c_fp, C.c_long, c_stream]),
 }

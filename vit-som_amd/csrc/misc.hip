@@ -265,3 +265,57 @@ int vsom_adamw_step(float* p, const float* g, float* m, float* v, const float* w
 }
 
 }  // extern "C"
+
+// ------------------------------------------------------------------ evaluation helpers (tools/evaluation.py)
+namespace vsom {
+// table[a[i] * nb + b[i]] += 1   (integer atomics: order-independent, bitwise reproducible)
+__global__ __launch_bounds__(256) void contingency_kernel(const int64_t* __restrict__ a, const int64_t* __restrict__ b,
+                                                          long n, int na, int nb, unsigned long long* __restrict__ table,
+                                                          int* __restrict__ bad) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int64_t x = a[i], y = b[i];
+        if (x < 0 || x >= na || y < 0 || y >= nb) { atomicAdd(bad, 1); continue; }
+        atomicAdd(table + x * nb + y, 1ULL);
+    }
+}
+// out[r] = first argmax_c X[r, c]   (torch.argmax semantics), one wave per row
+__global__ __launch_bounds__(256) void argmax_rows_kernel(const float* __restrict__ X, long ldx, int rows, int cols,
+                                                          int64_t* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int c = lane; c < cols; c += 64) {
+        const float v = X[(long)row * ldx + c];
+        if (v > best || (v == best && c < bi)) { best = v; bi = c; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    if (lane == 0) out[row] = bi == 0x7fffffff ? 0 : bi;
+}
+}  // namespace vsom
+
+extern "C" {
+
+int vsom_contingency(const int64_t* a, const int64_t* b, long n, int na, int nb, unsigned long long* table,
+                     int* out_of_range, vsom_stream_t stream) {
+    VSOM_REQUIRE(a && b && table && out_of_range, VSOM_EINVAL, "contingency: null pointer");
+    VSOM_REQUIRE(n >= 0 && na > 0 && nb > 0, VSOM_EINVAL, "contingency: bad sizes");
+    if (n == 0) return VSOM_OK;
+    hipLaunchKernelGGL(vsom::contingency_kernel, dim3(vsom::grid_for(n, 256, 2048)), dim3(256), 0, stream, a, b, n, na, nb,
+                       table, out_of_range);
+    VSOM_LAUNCH_CHECK("contingency_kernel");
+}
+
+int vsom_argmax_rows(const float* X, long ldx, int rows, int cols, int64_t* out, vsom_stream_t stream) {
+    VSOM_REQUIRE(X && out && rows > 0 && cols > 0 && ldx >= cols, VSOM_EINVAL, "argmax_rows: bad arguments");
+    hipLaunchKernelGGL(vsom::argmax_rows_kernel, dim3(vsom::cdiv(rows, 4)), dim3(256), 0, stream, X, ldx, rows, cols, out);
+    VSOM_LAUNCH_CHECK("argmax_rows_kernel");
+}
+
+}  // extern "C"

@@ -547,19 +547,47 @@ class FusedAdamW(torch.optim.Optimizer):
         # gradients are fully overwritten by every backward pass; nothing to clear
         return None
 
+    # torch.optim.AdamW-compatible state layout (per-parameter 'step' / 'exp_avg' / 'exp_avg_sq' in
+    # param_groups order), so optimizer states interchange with reference-written checkpoints
+    def _param_names_in_group_order(self):
+        name_of = {id(p): n for n, p in self._model._named_trainable()}
+        return [name_of[id(p)] for g in self.param_groups for p in g["params"]]
+
     def state_dict(self):
-        sd = super().state_dict()
-        sd["fused"] = {"step": self._step, "exp_avg": self._model.arena.exp_avg.clone(),
-                       "exp_avg_sq": self._model.arena.exp_avg_sq.clone()}
-        return sd
+        a = self._model.arena
+        names = self._param_names_in_group_order()
+        state = {}
+        if self._step > 0:
+            for i, n in enumerate(names):
+                state[i] = {"step": torch.tensor(float(self._step)), "exp_avg": a.view(a.exp_avg, n).clone(),
+                            "exp_avg_sq": a.view(a.exp_avg_sq, n).clone()}
+        groups, k = [], 0
+        for g in self.param_groups:
+            pg = {key: v for key, v in g.items() if key != "params"}
+            pg["params"] = list(range(k, k + len(g["params"])))
+            k += len(g["params"])
+            groups.append(pg)
+        return {"state": state, "param_groups": groups}
 
     def load_state_dict(self, sd):
-        fused = sd.pop("fused", None)
-        super().load_state_dict(sd)
-        if fused is not None:
-            self._step = int(fused["step"])
-            self._model.arena.exp_avg.copy_(fused["exp_avg"])
-            self._model.arena.exp_avg_sq.copy_(fused["exp_avg_sq"])
+        a = self._model.arena
+        names = self._param_names_in_group_order()
+        if len(sd["param_groups"]) != len(self.param_groups):
+            raise ValueError("FusedAdamW.load_state_dict: different number of parameter groups")
+        for g, sg in zip(self.param_groups, sd["param_groups"]):
+            for key, v in sg.items():
+                if key != "params":
+                    g[key] = v
+        steps = set()
+        a.exp_avg.zero_(); a.exp_avg_sq.zero_()
+        for i, st in sd["state"].items():
+            n = names[int(i)]
+            a.view(a.exp_avg, n).copy_(st["exp_avg"])
+            a.view(a.exp_avg_sq, n).copy_(st["exp_avg_sq"])
+            steps.add(int(float(st["step"])))
+        if len(steps) > 1:
+            raise ValueError("FusedAdamW.load_state_dict: parameters carry different step counts")
+        self._step = steps.pop() if steps else 0
 
 
 # ------------------------------------------------------------------------------------ autograd bridge
@@ -746,6 +774,15 @@ class ViTSOM(_Base):
         return cls, recon, logits, s.dist.clone(), s.bmu.clone()
 
     @torch.no_grad()
+    def predict(self, x):
+        """Inference fast path for tools/evaluation.py: encoder + SOM (+ cls head) only -- the decoder,
+        whose output evaluate_clustering / evaluate_classification never read, is skipped.  Returns
+        (bmu_indices [B] int64, logits [B,C] | None) as views of internal buffers (valid until the
+        next call)."""
+        x, a, s = self._run_forward(x, need_decoder=False)
+        return s.bmu, (a.logits if self.classification else None)
+
+    @torch.no_grad()
     def _forward_losses(self, x, y, gamma_t: float, T: float, want_grad: bool):
         """All forward kernels + both losses (+ loss-side gradients when want_grad).  Returns the
         total loss as a 0-dim device tensor; parts land in self._last."""
@@ -881,6 +918,41 @@ class ViTSOM(_Base):
                                                            0.5 * (math.cos(epoch / hp["total_epochs"] * math.pi) + 1)))
         scheduler = torch.optim.lr_scheduler.LambdaLR(optimizer, lr_lambda=lr_func)
         return [optimizer], [scheduler]
+
+    # -- checkpoints: Lightning's .ckpt layout --------------------------------------
+    def save_checkpoint(self, path, optimizer=None, scheduler=None, epoch=0, global_step=None):
+        """Write a file with the keys a Lightning ModelCheckpoint writes (train_vit_som.py:81-84):
+        state_dict (reference key names), hyper_parameters (= the config dict, vit_som.py:26),
+        optimizer_states / lr_schedulers, epoch, global_step."""
+        ckpt = {
+            "epoch": int(epoch), "global_step": int(self._it if global_step is None else global_step),
+            "pytorch-lightning_version": "2.2.1", "hparams_name": "config",
+            "state_dict": {k: v.detach().cpu().clone() for k, v in self.state_dict().items()},
+            "hyper_parameters": self.config,
+            "optimizer_states": [optimizer.state_dict()] if optimizer is not None else [],
+            "lr_schedulers": [scheduler.state_dict()] if scheduler is not None else [],
+        }
+        for st in ckpt["optimizer_states"]:
+            for s in st["state"].values():
+                for k2 in ("exp_avg", "exp_avg_sq"):
+                    s[k2] = s[k2].cpu()
+        os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+        torch.save(ckpt, path)
+        return path
+
+    @classmethod
+    def load_from_checkpoint(cls, checkpoint_path, config=None, device=None, map_location=None):
+        """ViTSOM.load_from_checkpoint(path, config=config) (train_vit_som.py:111).  Only loaders
+        that execute nothing from the file are used (torch.load(weights_only=True))."""
+        ckpt = torch.load(checkpoint_path, map_location="cpu", weights_only=True)
+        if config is None:
+            config = ckpt.get("hyper_parameters")
+            if config is None:
+                raise ValueError("checkpoint carries no hyper_parameters; pass config=")
+        model = cls(config, device=device)
+        model.load_state_dict(ckpt["state_dict"])
+        model._loaded_checkpoint = ckpt
+        return model
 
     def on_train_end(self):                                             # vit_som.py:165-172
         print(f"Peak GPU memory usage: {torch.cuda.max_memory_allocated() / 1e9:.4f} GB")

@@ -281,3 +281,21 @@ def reduce_slabs(slabs, out):
     nslabs, n = slabs.shape
     check(lib.vsom_reduce_slabs(ptr(slabs), slabs.stride(0), nslabs, ptr(out), n, stream()), "vsom_reduce_slabs")
     return out
+
+
+# ---------------------------------------------------------------- evaluation
+def contingency(a, b, table, bad):
+    """table[a[i], b[i]] += 1 (int64 device tensors; table is [na, nb] int64, accumulated)."""
+    assert a.dtype == torch.int64 and b.dtype == torch.int64 and table.dtype == torch.int64 and bad.dtype == torch.int32
+    assert a.is_cuda and a.is_contiguous() and b.is_contiguous() and table.is_contiguous() and a.numel() == b.numel()
+    na, nb = table.shape
+    check(lib.vsom_contingency(ptr(a), ptr(b), a.numel(), na, nb, ptr(table), ptr(bad), stream()), "vsom_contingency")
+    return table
+
+
+def argmax_rows(x, out):
+    rows, cols = x.shape
+    _f32(x, "x")
+    assert out.dtype == torch.int64
+    check(lib.vsom_argmax_rows(ptr(x), _rows(x), rows, cols, ptr(out), stream()), "vsom_argmax_rows")
+    return out
