@@ -1,8 +1,8 @@
-// Multi-head attention forward / backward for short ViT sequences (N = 17..257 tokens),
+// Multi-head attention forward / backward for short ViT sequences (N = 5..320 tokens),
 // exact fp32 on v_mfma_f32_16x16x4_f32.
 //
 // One workgroup per (image, head); the two [N, hd] operands every query/key tile needs stay
-// in LDS for the whole workgroup; each wave owns 16-row tiles.  Scores are computed
+// in LDS for the whole workgroup; each MFMA wave owns 16-row tiles.  Scores are computed
 // TRANSPOSED (rows = the LDS operand's 16 rows, columns = the wave's own 16 rows), so the
 // MFMA result layout (column on lane&15, 4 consecutive rows in the 4 registers of lane group
 // l>>4) is already the B-operand layout of the second product: probabilities never leave
@@ -13,9 +13,18 @@
 //   dKV  : S = Q k^T, dP = dO v^T, dS = P (dP - D) -> dV^T += dO^T P, dK^T += Q^T dS
 //
 // The backward recomputes P from the saved log-sum-exp (nothing of size N x N touches HBM).
+//
+// EXTRA mode (N = 16 m + 1: the ViT case, m*16 patch tokens + the CLS token).  Padding 65 -> 80
+// tokens would cost 800 MFMAs per head for 528 useful and a fifth wave doing 160 MFMAs for ONE
+// valid row.  Instead tokens 1..16m run as m full, unmasked MFMA tiles (m balanced waves) and token
+// 0 is the "extra" row/column: as a key/query it enters every tile wave through two VALU dot
+// products and rank-1 updates of the accumulators; as the wave's own row it is handled by one
+// additional wave with VALU only (lane per key for the dots, lane per channel for the sums).
 #include "common.h"
 
 namespace vsom {
+
+constexpr int MAXCH = 5;   // EXTRA mode: the VALU wave walks the rows in chunks of 64 -> N <= 320
 
 template <int HDP>
 struct ACfg {
@@ -38,26 +47,34 @@ __device__ __forceinline__ float group_max(float v) {
     v = fmaxf(v, __shfl_xor(v, 32, 64));
     return v;
 }
+// token index of row r of tile t
+template <bool EXTRA>
+__device__ __forceinline__ int tok(int t, int r) { return (EXTRA ? 1 : 0) + 16 * t + r; }
 
-// stage rows [0,N) of a [N, hd] slice (row stride `rs`) into lds[Np][S], zero padded
+// stage rows [0,N) of a [N, hd] slice (row stride `rs`) into lds[nrows][S], zero padded
 template <int HDP>
-__device__ __forceinline__ void stage_rows(float* lds, const float* __restrict__ src, long rs, int N, int Np,
+__device__ __forceinline__ void stage_rows(float* lds, const float* __restrict__ src, long rs, int N, int nrows,
                                            int hd) {
     constexpr int S = ACfg<HDP>::S;
     if constexpr (ACfg<HDP>::VEC) {
         constexpr int C4 = HDP / 4;
-        for (int idx = threadIdx.x; idx < Np * C4; idx += blockDim.x) {
+        for (int idx = threadIdx.x; idx < nrows * C4; idx += blockDim.x) {
             const int row = idx / C4, c4 = idx % C4;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (row < N) v = *reinterpret_cast<const f32x4*>(src + (long)row * rs + 4 * c4);
             *reinterpret_cast<f32x4*>(lds + row * S + 4 * c4) = v;
         }
     } else {
-        for (int idx = threadIdx.x; idx < Np * HDP; idx += blockDim.x) {
+        for (int idx = threadIdx.x; idx < nrows * HDP; idx += blockDim.x) {
             const int row = idx / HDP, c = idx % HDP;
             lds[row * S + c] = (row < N && c < hd) ? src[(long)row * rs + c] : 0.f;
         }
     }
+}
+// one row of hd floats -> lds[HDP] (zero padded)
+template <int HDP>
+__device__ __forceinline__ void stage_vec(float* lds, const float* __restrict__ src, int hd) {
+    for (int c = threadIdx.x; c < HDP; c += blockDim.x) lds[c] = (c < hd) ? src[c] : 0.f;
 }
 
 // per-lane operand values of one row for all NMM MFMAs.  Lane group qp supplies reduction index
@@ -83,30 +100,65 @@ __device__ __forceinline__ void load_frag(float (&f)[ACfg<HDP>::NMM], const floa
     }
 }
 
-// acc[4q'+reg][own row] = sum_d Y[16t + 4q'+reg][d] * own[row][d]
+// acc[4q'+reg][own row] = sum_d Y[row0 + 4q'+reg][d] * own[row][d]    (row0 = first token of the tile)
 template <int HDP>
-__device__ __forceinline__ f32x4 score_tile(const float* Ylds, int t, int r, int qp,
+__device__ __forceinline__ f32x4 score_tile(const float* Ylds, int row0, int r, int qp,
                                             const float (&bf)[ACfg<HDP>::NMM]) {
     float af[ACfg<HDP>::NMM];
-    load_frag<HDP>(af, Ylds + (16 * t + r) * ACfg<HDP>::S, qp, true, HDP);
+    load_frag<HDP>(af, Ylds + (row0 + r) * ACfg<HDP>::S, qp, true, HDP);
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int mm = 0; mm < ACfg<HDP>::NMM; ++mm) acc = mfma16(af[mm], bf[mm], acc);
     return acc;
 }
-
-// o[dt][d = 16dt + 4q'+reg][own row] += sum_{j in tile t} Z[j][d] * p[j][own row]
+// two score tiles with interleaved MFMAs (v_mfma_f32_16x16x4_f32: 32-cycle issue, 40-cycle result)
 template <int HDP>
-__device__ __forceinline__ void accum_tile(f32x4 (&o)[ACfg<HDP>::NDT], const float* Zlds, int t, int r, int qp,
+__device__ __forceinline__ void score_tile2(const float* Y0, int row0, const float (&b0)[ACfg<HDP>::NMM], const float* Y1,
+                                            int row1, const float (&b1)[ACfg<HDP>::NMM], int r, int qp, f32x4& acc0,
+                                            f32x4& acc1) {
+    float a0[ACfg<HDP>::NMM], a1[ACfg<HDP>::NMM];
+    load_frag<HDP>(a0, Y0 + (row0 + r) * ACfg<HDP>::S, qp, true, HDP);
+    load_frag<HDP>(a1, Y1 + (row1 + r) * ACfg<HDP>::S, qp, true, HDP);
+    acc0 = f32x4{0.f, 0.f, 0.f, 0.f};
+    acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int mm = 0; mm < ACfg<HDP>::NMM; ++mm) {
+        acc0 = mfma16(a0[mm], b0[mm], acc0);
+        acc1 = mfma16(a1[mm], b1[mm], acc1);
+    }
+}
+
+// o[dt][d = 16dt + 4q'+reg][own row] += sum_{j in tile} Z[row0 + j][d] * p[j][own row]
+template <int HDP>
+__device__ __forceinline__ void accum_tile(f32x4 (&o)[ACfg<HDP>::NDT], const float* Zlds, int row0, int r, int qp,
                                            f32x4 p) {
     constexpr int S = ACfg<HDP>::S;
 #pragma unroll
-    for (int dt = 0; dt < ACfg<HDP>::NDT; ++dt) {
+    for (int s = 0; s < 4; ++s) {                // s outer: the NDT accumulators form independent chains
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
+        for (int dt = 0; dt < ACfg<HDP>::NDT; ++dt) {
             float a = 0.f;
-            if (ACfg<HDP>::VEC || 16 * dt + r < HDP) a = Zlds[(16 * t + 4 * qp + s) * S + 16 * dt + r];
+            if (ACfg<HDP>::VEC || 16 * dt + r < HDP) a = Zlds[(row0 + 4 * qp + s) * S + 16 * dt + r];
             o[dt] = mfma16(a, p[s], o[dt]);
+        }
+    }
+}
+template <int HDP>
+__device__ __forceinline__ void accum_tile2(f32x4 (&o0)[ACfg<HDP>::NDT], const float* Z0, f32x4 p0,
+                                            f32x4 (&o1)[ACfg<HDP>::NDT], const float* Z1, f32x4 p1, int row0, int r,
+                                            int qp) {
+    constexpr int S = ACfg<HDP>::S;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+#pragma unroll
+        for (int dt = 0; dt < ACfg<HDP>::NDT; ++dt) {
+            float a0 = 0.f, a1 = 0.f;
+            if (ACfg<HDP>::VEC || 16 * dt + r < HDP) {
+                a0 = Z0[(row0 + 4 * qp + s) * S + 16 * dt + r];
+                a1 = Z1[(row0 + 4 * qp + s) * S + 16 * dt + r];
+            }
+            o0[dt] = mfma16(a0, p0[s], o0[dt]);
+            o1[dt] = mfma16(a1, p1[s], o1[dt]);
         }
     }
 }
@@ -128,51 +180,176 @@ __device__ __forceinline__ void store_rows(const f32x4 (&o)[ACfg<HDP>::NDT], flo
     }
 }
 
-// ------------------------------------------------------------------ forward
+// ---- EXTRA-token helpers (VALU) -----------------------------------------------------------------
+// full dot product of each of the wave's 16 own rows (fragments in registers) with ONE LDS row
 template <int HDP>
-__global__ __launch_bounds__(512) void attn_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+__device__ __forceinline__ float frag_dot_row(const float (&f)[ACfg<HDP>::NMM], const float* rowptr, int qp) {
+    float y[ACfg<HDP>::NMM];
+    load_frag<HDP>(y, rowptr, qp, true, HDP);
+    float s = 0.f;
+#pragma unroll
+    for (int mm = 0; mm < ACfg<HDP>::NMM; ++mm) s = fmaf(f[mm], y[mm], s);
+    return group_sum(s);
+}
+// o[dt][d][own row] += w[own row] * row[d]   (rank-1 update in the accumulator layout)
+template <int HDP>
+__device__ __forceinline__ void axpy_row(f32x4 (&o)[ACfg<HDP>::NDT], float w, const float* rowptr, int qp) {
+#pragma unroll
+    for (int dt = 0; dt < ACfg<HDP>::NDT; ++dt) {
+        const int d0 = 16 * dt + 4 * qp;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (ACfg<HDP>::VEC) {
+            v = *reinterpret_cast<const f32x4*>(rowptr + d0);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (d0 + e < HDP) v[e] = rowptr[d0 + e];
+        }
+        o[dt] += w * v;
+    }
+}
+// s[c] = x . Y[64c + lane]   (lane per row, rows beyond nrows give 0)
+template <int HDP>
+__device__ __forceinline__ void rows_dot(float (&s)[MAXCH], const float* x, const float* Y, int nrows, int lane) {
+    constexpr int S = ACfg<HDP>::S;
+#pragma unroll
+    for (int c = 0; c < MAXCH; ++c) {
+        float acc = 0.f;
+        const int row = 64 * c + lane;
+        if (64 * c < nrows && row < nrows) {
+#pragma unroll
+            for (int d4 = 0; d4 < HDP / 4; ++d4) {
+                const f32x4 y = *reinterpret_cast<const f32x4*>(Y + row * S + 4 * d4);
+                const f32x4 xv = *reinterpret_cast<const f32x4*>(x + 4 * d4);
+                acc = fmaf(y[0], xv[0], acc); acc = fmaf(y[1], xv[1], acc);
+                acc = fmaf(y[2], xv[2], acc); acc = fmaf(y[3], xv[3], acc);
+            }
+        }
+        s[c] = acc;
+    }
+}
+// sum_row w[row] * Z[row][d]   (lane per channel d < HDP)
+template <int HDP>
+__device__ __forceinline__ float rows_wsum(const float* w, const float* Z, int nrows, int d) {
+    constexpr int S = ACfg<HDP>::S;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int row = 0;
+    for (; row + 3 < nrows; row += 4) {
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(w + row);
+        a0 = fmaf(wv[0], Z[(row + 0) * S + d], a0);
+        a1 = fmaf(wv[1], Z[(row + 1) * S + d], a1);
+        a2 = fmaf(wv[2], Z[(row + 2) * S + d], a2);
+        a3 = fmaf(wv[3], Z[(row + 3) * S + d], a3);
+    }
+    for (; row < nrows; ++row) a0 = fmaf(w[row], Z[row * S + d], a0);
+    return (a0 + a1) + (a2 + a3);
+}
+__device__ __forceinline__ void lds_fence_wave() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+// LDS carve shared by the three kernels
+template <int HDP, bool EXTRA>
+struct Carve {
+    int ntile, nrows, nrp;
+    float *Y0, *Y1, *L0, *L1, *X0, *X1, *W1, *W2;
+    __device__ __forceinline__ Carve(float* smem, int N, bool with_stats) {
+        constexpr int S = ACfg<HDP>::S;
+        ntile = EXTRA ? (N - 1) >> 4 : (N + 15) >> 4;
+        nrows = EXTRA ? N : ntile << 4;
+        nrp = (nrows + 3) & ~3;
+        Y0 = smem;
+        Y1 = Y0 + nrows * S;
+        L0 = Y1 + nrows * S;
+        L1 = L0 + (with_stats ? nrp : 0);
+        X0 = L1 + (with_stats ? nrp : 0);
+        X1 = X0 + HDP;
+        W1 = X1 + HDP;
+        W2 = W1 + nrp;
+    }
+};
+
+// ------------------------------------------------------------------ forward
+template <int HDP, bool EXTRA>
+__global__ __launch_bounds__(576) void attn_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out,
                                                        float* __restrict__ lse, int N, int H, int hd,
                                                        float scale) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int S = ACfg<HDP>::S;
     constexpr int NDT = ACfg<HDP>::NDT;
     const int b = blockIdx.x / H, h = blockIdx.x % H;
     const int E = H * hd, E3 = 3 * E;
-    const int ntile = (N + 15) >> 4, Np = ntile << 4;
-    float* Ks = smem;
-    float* Vs = smem + Np * S;
+    const Carve<HDP, EXTRA> cv(smem, N, false);
+    const int ntile = cv.ntile;
+    float* Ks = cv.Y0;
+    float* Vs = cv.Y1;
     const float* base = qkv + (long)b * N * E3 + h * hd;
-    stage_rows<HDP>(Ks, base + E, E3, N, Np, hd);
-    stage_rows<HDP>(Vs, base + 2 * E, E3, N, Np, hd);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    const int tile_waves = nwaves - (EXTRA ? 1 : 0);
+    const bool extra_wave = EXTRA && wave == tile_waves;
+    const int r = lane & 15, qp = lane >> 4;
+    // the wave's first query fragment is requested BEFORE the K/V staging (latency overlaps it)
+    float qf[ACfg<HDP>::NMM];
+    if (!extra_wave) load_frag<HDP>(qf, base + (long)tok<EXTRA>(wave, r) * E3, qp, tok<EXTRA>(wave, r) < N, hd);
+    stage_rows<HDP>(Ks, base + E, E3, N, cv.nrows, hd);
+    stage_rows<HDP>(Vs, base + 2 * E, E3, N, cv.nrows, hd);
+    if (EXTRA) stage_vec<HDP>(cv.X0, base, hd);                       // q of token 0
     __syncthreads();
 
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
-    const int r = lane & 15, qp = lane >> 4;
-    for (int qt = wave; qt < ntile; qt += nwaves) {
-        const int query = 16 * qt + r;
+    if (extra_wave) {                                                  // token 0 as a query: VALU only
+        float s[MAXCH];
+        rows_dot<HDP>(s, cv.X0, Ks, N, lane);
+        float m = -INFINITY;
+#pragma unroll
+        for (int c = 0; c < MAXCH; ++c) { s[c] = (64 * c + lane < N) ? s[c] * scale : -INFINITY; m = fmaxf(m, s[c]); }
+        m = wave_max(m);
+        float l = 0.f;
+#pragma unroll
+        for (int c = 0; c < MAXCH; ++c) {
+            const float p = __expf(s[c] - m);
+            l += p;
+            if (64 * c + lane < N) cv.W1[64 * c + lane] = p;
+        }
+        l = wave_sum(l);
+        lds_fence_wave();
+        if (lane < HDP) {
+            const float o = rows_wsum<HDP>(cv.W1, Vs, N, lane) / l;
+            if (lane < hd) out[((long)b * N) * E + h * hd + lane] = o;
+        }
+        if (lane == 0) lse[((long)b * H + h) * N] = m + logf(l);
+        return;
+    }
+
+    for (int qt = wave; qt < ntile; qt += tile_waves) {
+        const int query = tok<EXTRA>(qt, r);
         const bool qok = query < N;
-        float qf[ACfg<HDP>::NMM];
-        load_frag<HDP>(qf, base + (long)query * E3, qp, qok, hd);
+        if (qt != wave) load_frag<HDP>(qf, base + (long)query * E3, qp, qok, hd);
         float m = -INFINITY, l = 0.f;
         f32x4 o[NDT];
 #pragma unroll
         for (int dt = 0; dt < NDT; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (EXTRA) {                                                   // token 0 as a key: running state starts from it
+            m = frag_dot_row<HDP>(qf, Ks, qp) * scale;
+            l = 1.0f;
+            axpy_row<HDP>(o, 1.0f, Vs, qp);
+        }
         for (int c0 = 0; c0 < ntile; c0 += 4) {
             f32x4 s[4];
             float cmax = -INFINITY;
 #pragma unroll
-            for (int tt = 0; tt < 4; ++tt) {
+            for (int tt = 0; tt < 4; tt += 2) {
                 const int t = c0 + tt;
-                if (t < ntile) {
-                    s[tt] = score_tile<HDP>(Ks, t, r, qp, qf);
+                if (t + 1 < ntile) score_tile2<HDP>(Ks, tok<EXTRA>(t, 0), qf, Ks, tok<EXTRA>(t + 1, 0), qf, r, qp, s[tt], s[tt + 1]);
+                else if (t < ntile) s[tt] = score_tile<HDP>(Ks, tok<EXTRA>(t, 0), r, qp, qf);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int key = 16 * t + 4 * qp + e;
-                        s[tt][e] = (key < N) ? s[tt][e] * scale : -INFINITY;
-                        cmax = fmaxf(cmax, s[tt][e]);
+                for (int u = 0; u < 2; ++u) {
+                    if (t + u < ntile) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int key = tok<EXTRA>(t + u, 4 * qp + e);
+                            s[tt + u][e] = (EXTRA || key < N) ? s[tt + u][e] * scale : -INFINITY;
+                            cmax = fmaxf(cmax, s[tt + u][e]);
+                        }
+                    } else {
+                        s[tt + u] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
                     }
-                } else {
-                    s[tt] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
                 }
             }
             cmax = group_max(cmax);
@@ -194,7 +371,7 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const float* __restrict__
             for (int dt = 0; dt < NDT; ++dt) o[dt] *= alpha;
 #pragma unroll
             for (int tt = 0; tt < 4; ++tt)
-                if (c0 + tt < ntile) accum_tile<HDP>(o, Vs, c0 + tt, r, qp, s[tt]);
+                if (c0 + tt < ntile) accum_tile<HDP>(o, Vs, tok<EXTRA>(c0 + tt, 0), r, qp, s[tt]);
         }
         const float inv = 1.0f / l;
 #pragma unroll
@@ -205,37 +382,75 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const float* __restrict__
 }
 
 // ------------------------------------------------------------------ backward: dQ (+ D = rowsum(dO * O))
-template <int HDP>
-__global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const float* __restrict__ qkv,
+template <int HDP, bool EXTRA>
+__global__ __launch_bounds__(576) void attn_bwd_dq_kernel(const float* __restrict__ qkv,
                                                           const float* __restrict__ out,
                                                           const float* __restrict__ dout,
                                                           const float* __restrict__ lse,
                                                           float* __restrict__ dqkv, float* __restrict__ delta,
                                                           int N, int H, int hd, float scale) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int S = ACfg<HDP>::S;
     constexpr int NDT = ACfg<HDP>::NDT;
     constexpr int NMM = ACfg<HDP>::NMM;
     const int b = blockIdx.x / H, h = blockIdx.x % H;
     const int E = H * hd, E3 = 3 * E;
-    const int ntile = (N + 15) >> 4, Np = ntile << 4;
-    float* Ks = smem;
-    float* Vs = smem + Np * S;
+    const Carve<HDP, EXTRA> cv(smem, N, false);
+    const int ntile = cv.ntile;
+    float* Ks = cv.Y0;
+    float* Vs = cv.Y1;
     const float* base = qkv + (long)b * N * E3 + h * hd;
-    stage_rows<HDP>(Ks, base + E, E3, N, Np, hd);
-    stage_rows<HDP>(Vs, base + 2 * E, E3, N, Np, hd);
+    const long obase = (long)b * N * E + h * hd;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    const int tile_waves = nwaves - (EXTRA ? 1 : 0);
+    const bool extra_wave = EXTRA && wave == tile_waves;
+    const int r = lane & 15, qp = lane >> 4;
+    float qf[NMM], dof[NMM], of[NMM];
+    if (!extra_wave) {
+        const int q0 = tok<EXTRA>(wave, r);
+        load_frag<HDP>(qf, base + (long)q0 * E3, qp, q0 < N, hd);
+        load_frag<HDP>(dof, dout + obase + (long)q0 * E, qp, q0 < N, hd);
+        load_frag<HDP>(of, out + obase + (long)q0 * E, qp, q0 < N, hd);
+    }
+    stage_rows<HDP>(Ks, base + E, E3, N, cv.nrows, hd);
+    stage_rows<HDP>(Vs, base + 2 * E, E3, N, cv.nrows, hd);
+    if (EXTRA) {
+        stage_vec<HDP>(cv.X0, base, hd);                               // q of token 0
+        stage_vec<HDP>(cv.X1, dout + obase, hd);                       // dO of token 0
+    }
     __syncthreads();
 
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
-    const int r = lane & 15, qp = lane >> 4;
-    for (int qt = wave; qt < ntile; qt += nwaves) {
-        const int query = 16 * qt + r;
+    if (extra_wave) {                                                  // dQ of token 0: VALU only
+        float d0 = (lane < hd) ? cv.X1[lane] * out[obase + lane] : 0.f;
+        const float D0 = wave_sum(d0);
+        const long srow = ((long)b * H + h) * N;
+        if (lane == 0) delta[srow] = D0;
+        const float l0 = lse[srow];
+        float s[MAXCH], dp[MAXCH];
+        rows_dot<HDP>(s, cv.X0, Ks, N, lane);
+        rows_dot<HDP>(dp, cv.X1, Vs, N, lane);
+#pragma unroll
+        for (int c = 0; c < MAXCH; ++c) {
+            if (64 * c + lane < N) {
+                const float p = __expf(s[c] * scale - l0);
+                cv.W1[64 * c + lane] = p * (dp[c] - D0) * scale;
+            }
+        }
+        lds_fence_wave();
+        if (lane < HDP) {
+            const float g = rows_wsum<HDP>(cv.W1, Ks, N, lane);
+            if (lane < hd) dqkv[(long)b * N * E3 + h * hd + lane] = g;
+        }
+        return;
+    }
+
+    for (int qt = wave; qt < ntile; qt += tile_waves) {
+        const int query = tok<EXTRA>(qt, r);
         const bool qok = query < N;
-        float qf[NMM], dof[NMM], of[NMM];
-        load_frag<HDP>(qf, base + (long)query * E3, qp, qok, hd);
-        const long orow = ((long)b * N + query) * E + h * hd;
-        load_frag<HDP>(dof, dout + orow, qp, qok, hd);
-        load_frag<HDP>(of, out + orow, qp, qok, hd);
+        if (qt != wave) {
+            load_frag<HDP>(qf, base + (long)query * E3, qp, qok, hd);
+            load_frag<HDP>(dof, dout + obase + (long)query * E, qp, qok, hd);
+            load_frag<HDP>(of, out + obase + (long)query * E, qp, qok, hd);
+        }
         float D = 0.f;
 #pragma unroll
         for (int mm = 0; mm < NMM; ++mm) D = fmaf(dof[mm], of[mm], D);
@@ -246,74 +461,125 @@ __global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const float* __restric
         f32x4 dq[NDT];
 #pragma unroll
         for (int dt = 0; dt < NDT; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (EXTRA) {                                                   // token 0 as a key
+            const float s0 = frag_dot_row<HDP>(qf, Ks, qp) * scale;
+            const float dp0 = frag_dot_row<HDP>(dof, Vs, qp);
+            const float p0 = __expf(s0 - lq);
+            axpy_row<HDP>(dq, p0 * (dp0 - D) * scale, Ks, qp);
+        }
         for (int t = 0; t < ntile; ++t) {
-            const f32x4 s = score_tile<HDP>(Ks, t, r, qp, qf);
-            const f32x4 dp = score_tile<HDP>(Vs, t, r, qp, dof);
+            f32x4 s, dp;
+            score_tile2<HDP>(Ks, tok<EXTRA>(t, 0), qf, Vs, tok<EXTRA>(t, 0), dof, r, qp, s, dp);
             f32x4 ds;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const int key = 16 * t + 4 * qp + e;
-                const float p = (key < N && qok) ? __expf(s[e] * scale - lq) : 0.f;
+                const int key = tok<EXTRA>(t, 4 * qp + e);
+                const float p = (EXTRA || (key < N && qok)) ? __expf(s[e] * scale - lq) : 0.f;
                 ds[e] = p * (dp[e] - D) * scale;
             }
-            accum_tile<HDP>(dq, Ks, t, r, qp, ds);
+            accum_tile<HDP>(dq, Ks, tok<EXTRA>(t, 0), r, qp, ds);
         }
         store_rows<HDP>(dq, dqkv + ((long)b * N + query) * E3 + h * hd, qp, qok, hd);
     }
 }
 
 // ------------------------------------------------------------------ backward: dK, dV
-template <int HDP>
-__global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const float* __restrict__ qkv,
+template <int HDP, bool EXTRA>
+__global__ __launch_bounds__(576) void attn_bwd_dkv_kernel(const float* __restrict__ qkv,
                                                            const float* __restrict__ dout,
                                                            const float* __restrict__ lse,
                                                            const float* __restrict__ delta,
                                                            float* __restrict__ dqkv, int N, int H, int hd,
                                                            float scale) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int S = ACfg<HDP>::S;
     constexpr int NDT = ACfg<HDP>::NDT;
     constexpr int NMM = ACfg<HDP>::NMM;
     const int b = blockIdx.x / H, h = blockIdx.x % H;
     const int E = H * hd, E3 = 3 * E;
-    const int ntile = (N + 15) >> 4, Np = ntile << 4;
-    float* Qs = smem;
-    float* Ds = smem + Np * S;
-    float* Ls = smem + 2 * Np * S;
-    float* Es = Ls + Np;
+    const Carve<HDP, EXTRA> cv(smem, N, true);
+    const int ntile = cv.ntile;
+    float* Qs = cv.Y0;
+    float* Ds = cv.Y1;
+    float* Ls = cv.L0;
+    float* Es = cv.L1;
     const float* base = qkv + (long)b * N * E3 + h * hd;
-    stage_rows<HDP>(Qs, base, E3, N, Np, hd);
-    stage_rows<HDP>(Ds, dout + (long)b * N * E + h * hd, E, N, Np, hd);
-    for (int i = threadIdx.x; i < Np; i += blockDim.x) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    const int tile_waves = nwaves - (EXTRA ? 1 : 0);
+    const bool extra_wave = EXTRA && wave == tile_waves;
+    const int r = lane & 15, qp = lane >> 4;
+    float kf[NMM], vf[NMM];
+    if (!extra_wave) {
+        const int k0 = tok<EXTRA>(wave, r);
+        load_frag<HDP>(kf, base + (long)k0 * E3 + E, qp, k0 < N, hd);
+        load_frag<HDP>(vf, base + (long)k0 * E3 + 2 * E, qp, k0 < N, hd);
+    }
+    stage_rows<HDP>(Qs, base, E3, N, cv.nrows, hd);
+    stage_rows<HDP>(Ds, dout + (long)b * N * E + h * hd, E, N, cv.nrows, hd);
+    for (int i = threadIdx.x; i < cv.nrp; i += blockDim.x) {
         const long srow = ((long)b * H + h) * N + i;
         Ls[i] = (i < N) ? lse[srow] : 0.f;
         Es[i] = (i < N) ? delta[srow] : 0.f;
     }
+    if (EXTRA) {
+        stage_vec<HDP>(cv.X0, base + E, hd);                           // k of token 0
+        stage_vec<HDP>(cv.X1, base + 2 * E, hd);                       // v of token 0
+    }
     __syncthreads();
 
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
-    const int r = lane & 15, qp = lane >> 4;
-    for (int kt = wave; kt < ntile; kt += nwaves) {
-        const int key = 16 * kt + r;
+    if (extra_wave) {                                                  // dK, dV of token 0: VALU only
+        float s[MAXCH], dp[MAXCH];
+        rows_dot<HDP>(s, cv.X0, Qs, N, lane);                          // s_j = q_j . k_0
+        rows_dot<HDP>(dp, cv.X1, Ds, N, lane);                         // dp_j = dO_j . v_0
+#pragma unroll
+        for (int c = 0; c < MAXCH; ++c) {
+            const int j = 64 * c + lane;
+            if (j < N) {
+                const float p = __expf(s[c] * scale - Ls[j]);
+                cv.W1[j] = p;
+                cv.W2[j] = p * (dp[c] - Es[j]) * scale;
+            }
+        }
+        lds_fence_wave();
+        if (lane < HDP) {
+            const float gv = rows_wsum<HDP>(cv.W1, Ds, N, lane);
+            const float gk = rows_wsum<HDP>(cv.W2, Qs, N, lane);
+            if (lane < hd) {
+                float* drow = dqkv + (long)b * N * E3 + h * hd;
+                drow[E + lane] = gk;
+                drow[2 * E + lane] = gv;
+            }
+        }
+        return;
+    }
+
+    for (int kt = wave; kt < ntile; kt += tile_waves) {
+        const int key = tok<EXTRA>(kt, r);
         const bool kok = key < N;
-        float kf[NMM], vf[NMM];
-        load_frag<HDP>(kf, base + (long)key * E3 + E, qp, kok, hd);
-        load_frag<HDP>(vf, base + (long)key * E3 + 2 * E, qp, kok, hd);
+        if (kt != wave) {
+            load_frag<HDP>(kf, base + (long)key * E3 + E, qp, kok, hd);
+            load_frag<HDP>(vf, base + (long)key * E3 + 2 * E, qp, kok, hd);
+        }
         f32x4 dk[NDT], dv[NDT];
 #pragma unroll
         for (int dt = 0; dt < NDT; ++dt) { dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        if (EXTRA) {                                                   // token 0 as a query
+            const float s0 = frag_dot_row<HDP>(kf, Qs, qp) * scale;
+            const float dp0 = frag_dot_row<HDP>(vf, Ds, qp);
+            const float p0 = __expf(s0 - Ls[0]);
+            axpy_row<HDP>(dv, p0, Ds, qp);
+            axpy_row<HDP>(dk, p0 * (dp0 - Es[0]) * scale, Qs, qp);
+        }
         for (int t = 0; t < ntile; ++t) {
-            const f32x4 s = score_tile<HDP>(Qs, t, r, qp, kf);      // rows: queries of tile t, col: own key
-            const f32x4 dp = score_tile<HDP>(Ds, t, r, qp, vf);
+            f32x4 s, dp;                                              // rows: queries of tile t, col: own key
+            score_tile2<HDP>(Qs, tok<EXTRA>(t, 0), kf, Ds, tok<EXTRA>(t, 0), vf, r, qp, s, dp);
             f32x4 p, ds;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const int query = 16 * t + 4 * qp + e;
-                p[e] = (query < N && kok) ? __expf(s[e] * scale - Ls[query]) : 0.f;
+                const int query = tok<EXTRA>(t, 4 * qp + e);
+                p[e] = (EXTRA || (query < N && kok)) ? __expf(s[e] * scale - Ls[query]) : 0.f;
                 ds[e] = p[e] * (dp[e] - Es[query]) * scale;
             }
-            accum_tile<HDP>(dv, Ds, t, r, qp, p);
-            accum_tile<HDP>(dk, Qs, t, r, qp, ds);
+            accum_tile2<HDP>(dv, Ds, p, dk, Qs, ds, tok<EXTRA>(t, 0), r, qp);
         }
         float* drow = dqkv + ((long)b * N + key) * E3 + h * hd;
         store_rows<HDP>(dk, drow + E, qp, kok, hd);
@@ -321,8 +587,14 @@ __global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const float* __restri
     }
 }
 
-static int attn_waves(int N) {
-    const int ntile = cdiv(N, 16);
+// ------------------------------------------------------------------ host side
+// (A persistent variant -- workgroups looping over (image, head) items with register prefetch of
+// the next item's rows -- was measured and rejected: the extra registers drop residency from 3-4 to
+// 2 workgroups per CU and N = 65 got slower, 42 -> 55 us per forward layer.)
+static bool use_extra(int N) { return N >= 17 && (N % 16) == 1 && N <= 64 * MAXCH; }
+static int attn_tiles(int N) { return use_extra(N) ? (N - 1) / 16 : cdiv(N, 16); }
+static int attn_waves(int N) {          // MFMA (tile) waves; EXTRA mode adds one VALU wave
+    const int ntile = attn_tiles(N);
     const int rounds = cdiv(ntile, 8);
     return cdiv(ntile, rounds);
 }
@@ -333,28 +605,41 @@ static int attn_hdp(int hd) {
     return 0;
 }
 static size_t attn_lds_bytes(int N, int hdp, bool with_stats) {
-    const int Np = cdiv(N, 16) * 16;
-    return ((size_t)2 * Np * (hdp + 4) + (with_stats ? 2 * Np : 0)) * sizeof(float);
+    const int nrows = use_extra(N) ? N : cdiv(N, 16) * 16;
+    const int nrp = (nrows + 3) & ~3;
+    return ((size_t)2 * nrows * (hdp + 4) + (with_stats ? 2 * nrp : 0) + 2 * hdp + 2 * nrp) * sizeof(float);
 }
 
+template <int HDP, bool EXTRA>
+static int launch_fwd_t(const float* qkv, float* out, float* lse, int B, int N, int H, int hd, hipStream_t st) {
+    const size_t lds = attn_lds_bytes(N, HDP, false);
+    hipLaunchKernelGGL((attn_fwd_kernel<HDP, EXTRA>), dim3(B * H), dim3(64 * (attn_waves(N) + (EXTRA ? 1 : 0))), lds, st, qkv,
+                       out, lse, N, H, hd, 1.0f / sqrtf((float)hd));
+    VSOM_LAUNCH_CHECK("attn_fwd_kernel");
+}
+template <int HDP, bool EXTRA>
+static int launch_bwd_t(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv,
+                        float* delta, int B, int N, int H, int hd, hipStream_t st) {
+    const float scale = 1.0f / sqrtf((float)hd);
+    const dim3 block(64 * (attn_waves(N) + (EXTRA ? 1 : 0)));
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<HDP, EXTRA>), dim3(B * H), block, attn_lds_bytes(N, HDP, false), st, qkv, out, dout,
+                       lse, dqkv, delta, N, H, hd, scale);
+    int rc = hip_status(hipGetLastError(), "attn_bwd_dq_kernel");
+    if (rc) return rc;
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<HDP, EXTRA>), dim3(B * H), block, attn_lds_bytes(N, HDP, true), st, qkv, dout, lse,
+                       delta, dqkv, N, H, hd, scale);
+    VSOM_LAUNCH_CHECK("attn_bwd_dkv_kernel");
+}
 template <int HDP>
 static int launch_fwd(const float* qkv, float* out, float* lse, int B, int N, int H, int hd, hipStream_t st) {
-    const size_t lds = attn_lds_bytes(N, HDP, false);
-    hipLaunchKernelGGL(attn_fwd_kernel<HDP>, dim3(B * H), dim3(64 * attn_waves(N)), lds, st, qkv, out, lse, N, H, hd,
-                       1.0f / sqrtf((float)hd));
-    VSOM_LAUNCH_CHECK("attn_fwd_kernel");
+    return use_extra(N) ? launch_fwd_t<HDP, true>(qkv, out, lse, B, N, H, hd, st)
+                        : launch_fwd_t<HDP, false>(qkv, out, lse, B, N, H, hd, st);
 }
 template <int HDP>
 static int launch_bwd(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv,
                       float* delta, int B, int N, int H, int hd, hipStream_t st) {
-    const float scale = 1.0f / sqrtf((float)hd);
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<HDP>, dim3(B * H), dim3(64 * attn_waves(N)), attn_lds_bytes(N, HDP, false),
-                       st, qkv, out, dout, lse, dqkv, delta, N, H, hd, scale);
-    int rc = hip_status(hipGetLastError(), "attn_bwd_dq_kernel");
-    if (rc) return rc;
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel<HDP>, dim3(B * H), dim3(64 * attn_waves(N)), attn_lds_bytes(N, HDP, true),
-                       st, qkv, dout, lse, delta, dqkv, N, H, hd, scale);
-    VSOM_LAUNCH_CHECK("attn_bwd_dkv_kernel");
+    return use_extra(N) ? launch_bwd_t<HDP, true>(qkv, out, dout, lse, dqkv, delta, B, N, H, hd, st)
+                        : launch_bwd_t<HDP, false>(qkv, out, dout, lse, dqkv, delta, B, N, H, hd, st);
 }
 
 static int attn_check(const char* who, int B, int N, int H, int hd, int* hdp) {
