@@ -210,3 +210,74 @@ def test_use_reduced_cls_token_som():
     for n, p in m.named_parameters():
         if p.requires_grad:
             assert rel_err(p.grad.cpu(), G[n]) < 1e-4 or float((p.grad.cpu() - G[n]).abs().max()) < 1e-9, n
+
+
+def _shape_case(cfg, B, seed, it=30, n_train=100000, est=400, grad_tol=2e-4):
+    from oracle import vitsom_oracle as O
+    d = O.Dims(cfg)
+    P = O.init_params(cfg, seed=seed)
+    x, y = O.synthetic_batch(d, B, seed=seed + 1)
+    total, parts, G = O.loss_and_grads(P, x, y, d, it, n_train, est)
+    m = build(cfg, P)
+    m._it = it
+    m.set_schedule(n_train, est)
+    loss = m.training_step((x.to(DEV), y.to(DEV)), 0)
+    s = m._ctx[2]
+    assert abs(float(loss) - float(total)) < 1e-4
+    assert torch.allclose(s.dist.cpu(), parts["dist"], atol=2e-5)
+    assert bmu_ok(s.bmu.cpu(), parts["dist"].double())
+    if m.classification:
+        assert torch.allclose(m._ctx[1].logits.cpu(), parts["logits"], atol=1e-4)
+    loss.backward()
+    if torch.equal(s.bmu.cpu(), parts["bmu"]):
+        for n, p in m.named_parameters():
+            if p.requires_grad:
+                e = rel_err(p.grad.cpu(), G[n])
+                assert e < grad_tol or float((p.grad.cpu() - G[n]).abs().max()) < 1e-9, (n, e)
+    return m
+
+
+def test_c4_shapes_cifar100_classification_head():
+    """BASELINE config c4: vit_som-cls, CIFAR-100 (100 classes), 4x4 SOM (K=16, HBM-bound BMU shape)."""
+    from oracle.gen_golden import make_config
+    cfg = make_config(3, 32, 4, 192, 2, 3, 96, 2, (4, 4), 100, 24, gamma=0.01, Tmax=4.0, Tmin=0.1)
+    _shape_case(cfg, 24, seed=21)
+
+
+def test_c5_shapes_tiny_imagenet_40x40():
+    """BASELINE config c5: Tiny-ImageNet 64x64 -> N=257 tokens, L=49152, 40x40 SOM (the largest shapes)."""
+    from oracle.gen_golden import make_config
+    cfg = make_config(3, 64, 4, 192, 1, 3, 96, 1, (40, 40), 0, 4, gamma=0.01, Tmax=4.0, Tmin=0.1)
+    m = _shape_case(cfg, 4, seed=31, grad_tol=3e-4)
+    assert m.som_layer.latent_dim == 49152 and m.vit.patch_embed.num_patches == 256
+
+
+@pytest.mark.parametrize("B", [1, 3, 7])
+def test_small_and_odd_batches(B):
+    from oracle import vitsom_oracle as O
+    z, cfg = load_golden("ref_cluster_tiny")
+    P = golden_params(z)
+    d = O.Dims(cfg)
+    x, y = O.synthetic_batch(d, B, seed=B)
+    total, parts, G = O.loss_and_grads(P, x, y, d, 7, 60, 40)
+    m = build(cfg, P)
+    m.set_schedule(60, 40)
+    loss = m.training_step((x.to(DEV), y.to(DEV)), 0)
+    loss.backward()
+    assert abs(float(loss) - float(total)) < 2e-5
+    assert torch.equal(m._ctx[2].bmu.cpu(), parts["bmu"])
+    for n, p in m.named_parameters():
+        if p.requires_grad:
+            assert rel_err(p.grad.cpu(), G[n]) < 1e-4 or float((p.grad.cpu() - G[n]).abs().max()) < 1e-9, n
+
+
+def test_bad_inputs_fail_loudly():
+    from vit_som_amd._lib import VsomError
+    z, cfg = load_golden("ref_cluster_tiny")
+    m = build(cfg, golden_params(z))
+    with pytest.raises((VsomError, ValueError, RuntimeError)):
+        m(torch.empty(0, 1, 8, 8, device=DEV))                       # empty batch
+    with pytest.raises(ValueError):
+        m(torch.zeros(2, 3, 8, 8, device=DEV))                       # wrong channel count
+    with pytest.raises(ValueError):
+        m(torch.zeros(2, 1, 16, 16, device=DEV))                     # wrong image size
