@@ -178,6 +178,87 @@ void run_glds(const char* tag, const float* A, const float* B, float* C, float* 
     printf("%-28s tile %dx%d waves %dx%d occ %d: %7.1f us  %6.1f TF   (max |diff| vs reg-staged %.3g)\n", tag, BM, BN, WAVES_M, WAVES_N, OCC, best * 1e3, 2.0 * M * N * K / best / 1e9, md);
 }
 
+// ---- variant: persistent workgroups, natural loop nest, cross-tile prefetch -------------------------------------
+template <int WM, int WN, int WAVES_M, int WAVES_N, int OCC>
+__global__ __launch_bounds__(WAVES_M * WAVES_N * 64, OCC) void lab_persist(const float* __restrict__ A, const float* __restrict__ B,
+                                                                      float* __restrict__ C, int M, int N, int K) {
+    constexpr int NT = WAVES_M * WAVES_N * 64;
+    constexpr int BM = WAVES_M * WM * 32, BN = WAVES_N * WN * 32;
+    constexpr int RPP = NT / 8;
+    __shared__ __attribute__((aligned(16))) float lds[(BM + BN) * 36];
+    float* As = lds; float* Bs = lds + BM * 36;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, r = lane & 31, h = lane >> 5;
+    const int wm0 = (wave / WAVES_N) * WM * 32, wn0 = (wave % WAVES_N) * WN * 32;
+    const int tiles_n = N / BN, ntiles = (M / BM) * tiles_n;
+    const int nk = K / 32;
+    f32x4 sa[BM / RPP], sb[BN / RPP];
+    auto gload = [&](int tile, int k0) {
+        const int bm0 = (tile / tiles_n) * BM, bn0 = (tile % tiles_n) * BN;
+        const float* ap = A + (long)(bm0 + (t >> 3)) * K + ((t & 7) << 2) + k0;
+        const float* bp = B + (long)(bn0 + (t >> 3)) * K + ((t & 7) << 2) + k0;
+#pragma unroll
+        for (int p = 0; p < BM / RPP; ++p) sa[p] = *(const f32x4*)(ap + (long)p * RPP * K);
+#pragma unroll
+        for (int p = 0; p < BN / RPP; ++p) sb[p] = *(const f32x4*)(bp + (long)p * RPP * K);
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int p = 0; p < BM / RPP; ++p) *(f32x4*)(As + (p * RPP + (t >> 3)) * 36 + ((t & 7) << 2)) = sa[p];
+#pragma unroll
+        for (int p = 0; p < BN / RPP; ++p) *(f32x4*)(Bs + (p * RPP + (t >> 3)) * 36 + ((t & 7) << 2)) = sb[p];
+    };
+    int tile = blockIdx.x;
+    if (tile < ntiles) { gload(tile, 0); lstore(); }
+    __syncthreads();
+    for (; tile < ntiles; tile += gridDim.x) {
+        const int bm0 = (tile / tiles_n) * BM, bn0 = (tile % tiles_n) * BN;
+        f32x16 acc[WM][WN];
+        for (int i = 0; i < WM; ++i) for (int j = 0; j < WN; ++j) for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+        const int ntile = tile + gridDim.x;
+        for (int kt = 0; kt < nk; ++kt) {
+            const bool more = (kt + 1 < nk) || (ntile < ntiles);
+            if (kt + 1 < nk) gload(tile, (kt + 1) * 32); else if (ntile < ntiles) gload(ntile, 0);
+#pragma unroll
+            for (int kb = 0; kb < 32; kb += 8) {
+                f32x4 a[WM], b[WN];
+#pragma unroll
+                for (int i = 0; i < WM; ++i) a[i] = *(const f32x4*)(As + (wm0 + i * 32 + r) * 36 + kb + 4 * h);
+#pragma unroll
+                for (int j = 0; j < WN; ++j) b[j] = *(const f32x4*)(Bs + (wn0 + j * 32 + r) * 36 + kb + 4 * h);
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int i = 0; i < WM; ++i)
+#pragma unroll
+                        for (int j = 0; j < WN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
+            }
+            __syncthreads();
+            if (more) { lstore(); __syncthreads(); }
+        }
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const int m = bm0 + wm0 + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * h, n = bn0 + wn0 + j * 32 + r;
+                    C[(long)m * N + n] = acc[i][j][v];
+                }
+    }
+}
+template <int WM, int WN, int WAVES_M, int WAVES_N, int OCC>
+void run_persist(const char* tag, const float* A, const float* B, float* C, float* Cref, int M, int N, int K, int grid) {
+    auto go = [&]() { hipLaunchKernelGGL((lab_persist<WM, WN, WAVES_M, WAVES_N, OCC>), dim3(grid), dim3(WAVES_M * WAVES_N * 64), 0, 0, A, B, C, M, N, K); };
+    go(); hipDeviceSynchronize();
+    std::vector<float> x(1 << 16), y(1 << 16);
+    hipMemcpy(x.data(), C + 12345, x.size() * 4, hipMemcpyDeviceToHost); hipMemcpy(y.data(), Cref + 12345, y.size() * 4, hipMemcpyDeviceToHost);
+    double md = 0; for (size_t i = 0; i < x.size(); ++i) md = fmax(md, fabs((double)x[i] - y[i]));
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    float best = 1e9;
+    for (int r = 0; r < 5; ++r) { hipEventRecord(e0); for (int i = 0; i < 5; ++i) go(); hipEventRecord(e1); hipEventSynchronize(e1); float ms; hipEventElapsedTime(&ms, e0, e1); if (ms / 5 < best) best = ms / 5; }
+    printf("%-28s grid %4d occ %d: %7.1f us  %6.1f TF   (max |diff| %.3g)\n", tag, grid, OCC, best * 1e3, 2.0 * M * N * K / best / 1e9, md);
+}
+
 int main() {
     const int M = 33280, N = 576, K = 192;
     float *A, *B, *C; hipMalloc(&A, (size_t)M * K * 4); hipMalloc(&B, (size_t)N * K * 4); hipMalloc(&C, (size_t)M * N * 4);
@@ -191,6 +272,10 @@ int main() {
     run<1, 2, 4, 1, 8, 1>("mfma+epilogue", A, B, C, M, N, K);
     float* C2; hipMalloc(&C2, (size_t)M * N * 4);
     run<1, 2, 4, 1, 15, 1>("full (reference out)", A, B, C2, M, N, K);
+    run_persist<1, 2, 4, 1, 1>("persist natural", A, B, C, C2, M, N, K, 768);
+    run_persist<1, 2, 4, 1, 1>("persist natural", A, B, C, C2, M, N, K, 780);
+    run_persist<1, 2, 4, 1, 1>("persist natural", A, B, C, C2, M, N, K, 1024);
+    run_persist<1, 2, 4, 1, 1>("persist natural", A, B, C, C2, M, N, K, 1170);
     run_glds<1, 2, 4, 1, 1>("glds dbuf", A, B, C, C2, M, N, K);
     run_glds<1, 2, 4, 1, 3>("glds dbuf", A, B, C, C2, M, N, K);
     run_glds<1, 2, 4, 1, 4>("glds dbuf", A, B, C, C2, M, N, K);

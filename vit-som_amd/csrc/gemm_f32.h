@@ -391,5 +391,6 @@ int reduce_slabs2_internal(const float* slabs, long stride, int nslabs, float* o
                            long n2, hipStream_t stream);
 int sum_partials(const float* part, int n, float* out, hipStream_t stream);
 int choose_splits(int tiles, int ktiles, int max_splits, bool prefer_xcd_multiple = false);
+int gemm_tile_m(bool a_kc, bool b_kc, int M);
 
 }  // namespace vsom

@@ -19,9 +19,18 @@ const char* last_error() { return g_err; }
 // workgroups per CU instead of two and half the epilogue per workgroup.
 static long operand_bytes(long rows, long ld, long cols) { return ((rows - 1) * ld + cols) * 4; }
 
+// Tile height for a GEMM: 128 rows normally; the k-strided ("TN") weight-gradient GEMMs also have a
+// 64 x 64 tile, used when their output height (192 = proj / fc2 rows, 96, ...) would otherwise pad
+// 128-row tiles by >= 10 %.
+int gemm_tile_m(bool a_kc, bool b_kc, int M) {
+    if (a_kc || b_kc) return 128;
+    const double w128 = (double)cdiv(M, 128) * 128, w64 = (double)cdiv(M, 64) * 64;
+    return (w128 > 1.10 * w64) ? 64 : 128;
+}
+
 template <bool A_KC, bool B_KC, int EPI>
 static int launch_t(GemmP& g, int splits, hipStream_t stream) {
-    const int BM = 128, BN = 64;
+    const int BM = gemm_tile_m(A_KC, B_KC, g.M), BN = 64;
     const int tiles = cdiv(g.M, BM) * cdiv(g.N, BN);
     dim3 grid(tiles * splits, 1, 1), block(256);
     // extent of each operand in bytes; rows of a k-strided A may be remapped (a_seg)
@@ -32,6 +41,13 @@ static int launch_t(GemmP& g, int splits, hipStream_t stream) {
     const bool fast = g.a_vec && g.b_vec && (a_cols % 4 == 0) && (b_cols % 4 == 0) && ab < 0xFFFF0000L && bb < 0xFFFF0000L;
     g.a_bytes = (unsigned)ab; g.b_bytes = (unsigned)bb;
     g.n_major = bb > ab;        // share the larger operand's panel between neighbouring workgroups
+    if constexpr (!A_KC && !B_KC) {
+        if (BM == 64) {
+            if (fast) hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, 1, 1, 2, 2, EPI, true>), grid, block, 0, stream, g);
+            else hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, 1, 1, 2, 2, EPI, false>), grid, block, 0, stream, g);
+            VSOM_LAUNCH_CHECK("gemm_f32_kernel");
+        }
+    }
     if (fast)
         hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, 1, 2, 4, 1, EPI, true>), grid, block, 0, stream, g);
     else
@@ -192,7 +208,7 @@ int choose_splits(int tiles, int ktiles, int max_splits, bool prefer_xcd_multipl
     return best_s;
 }
 static int bwd_weight_splits(int M, int N, int K) {
-    return choose_splits(cdiv(N, 128) * cdiv(K, 64), cdiv(M, 32), 128);
+    return choose_splits(cdiv(N, gemm_tile_m(false, false, N)) * cdiv(K, 64), cdiv(M, 32), 128);
 }
 static long pad4(long n) { return (n + 3) & ~3L; }
 
