@@ -149,6 +149,10 @@ def main():
                                    "decoder), 40x40 cosine SOM on the flattened patch tokens (L=12288), clustering loss "
                                    "L1(recon)+gamma*SOM, AdamW, random-init weights",
                        "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}",
+                       "gemm_arithmetic": ("fp32 in/out; nn.Linear GEMMs on bf16 MFMA from an EXACT 3-piece bf16 split of "
+                                           "each fp32 operand (6 products, fp32 accumulate; error <= fp32 MFMA's); "
+                                           "BMU distance GEMM on f32 MFMA") if ops.get_gemm_mode() == ops.GEMM_SPLIT_BF16
+                                          else "f32 MFMA everywhere",
                        "final_loss": round(final_loss, 6)},
             "roofline": {"kernel": "gemm_f32_kernel<true,true,1,2,4,1,6,true> (BMU distance pass: X[B,L] . W[K,L]^T, split over L)",
                          "bound": "mfma", "achieved": round(bmu_flops / t_s / 1e12, 3), "peak": F32_MFMA_PEAK_TFLOPS,

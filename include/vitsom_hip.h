@@ -64,6 +64,30 @@ int vsom_linear_residual_fwd(const float* X, long ldx, const float* W, const flo
 int vsom_linear_bwd_input(const float* dY, long lddy, const float* W, float* dX, long lddx, int M,
                           int N, int K, int accumulate, const float* gelu_grad, vsom_stream_t stream);
 
+/* Same product from a TRANSPOSED weight copy Wt[K,N] (row-major, ld = N): both operands are then
+ * contiguous along the reduction and the GEMM runs on the same kernel family as the forward
+ * Linear (vsom_transpose_many keeps the copies current). */
+int vsom_linear_bwd_input_t(const float* dY, long lddy, const float* Wt, float* dX, long lddx, int M,
+                            int N, int K, int accumulate, const float* gelu_grad, vsom_stream_t stream);
+
+/* Batched 2-D transpose: for i < count, dst_base[dst_off_i + c*rows_i + r] = src_base[src_off_i + r*cols_i + c].
+ * `table` is a DEVICE array of count x 4 int64 {src_off, dst_off, rows, cols} (offsets in floats);
+ * max_rows / max_cols bound every entry (they size the grid). */
+int vsom_transpose_many(const float* src_base, float* dst_base, const long long* table, int count,
+                        int max_rows, int max_cols, vsom_stream_t stream);
+
+/* Arithmetic of the nn.Linear-shaped GEMMs (vsom_linear_*_fwd, vsom_linear_bwd_input_t,
+ * vsom_patch_embed_fwd).  Both modes deliver fp32-accurate results from fp32 operands:
+ *   VSOM_GEMM_F32        v_mfma_f32_32x32x2_f32, bitwise an fmaf chain;
+ *   VSOM_GEMM_SPLIT_BF16 (default) every operand split exactly into three bf16 pieces, the six
+ *                        leading cross products on v_mfma_f32_32x32x16_bf16 (csrc/gemm_x6.h):
+ *                        dropped terms < 2^-22 relative, 2.7x fewer matrix-core cycles.
+ * The BMU distance GEMM always uses VSOM_GEMM_F32.  Process-wide; returns VSOM_EINVAL on an unknown mode. */
+#define VSOM_GEMM_F32 0
+#define VSOM_GEMM_SPLIT_BF16 1
+int vsom_set_gemm_mode(int mode);
+int vsom_get_gemm_mode(void);
+
 /* dW[N,K] = dY[M,N]^T * X[M,K] ;  db[N] = column sums of dY (db may be NULL)
  * -- autograd of nn.Linear w.r.t. weight/bias.  The reduction over the M token rows is split
  * across workgroups into fp32 slabs in `ws` and summed in a fixed order (deterministic). */

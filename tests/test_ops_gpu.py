@@ -35,13 +35,23 @@ def dev(t):
     return t.to(DEV)
 
 
-# fp32 GEMM tolerance: relative Frobenius error vs an fp64 reference
+# fp32 GEMM tolerance: relative Frobenius error vs an fp64 reference -- the SAME bound for the
+# exact-f32 MFMA engine and the split-bf16 engine (both are fp32-accurate)
 GEMM_TOL = 2e-6
+
+
+@pytest.fixture(params=["split_bf16", "f32"])
+def gemm_mode(request, ops):
+    """Run a test under both arithmetic modes of the nn.Linear-shaped GEMMs."""
+    prev = ops.get_gemm_mode()
+    ops.set_gemm_mode(ops.GEMM_SPLIT_BF16 if request.param == "split_bf16" else ops.GEMM_F32)
+    yield request.param
+    ops.set_gemm_mode(prev)
 
 
 @pytest.mark.parametrize("M,N,K,ldpad", [(70, 50, 48, 0), (300, 192, 192, 0), (257, 576, 192, 8), (33, 10, 24, 0),
                                           (130, 96, 4, 0), (64, 768, 192, 0), (5, 3, 2, 0), (128, 128, 33, 3)])
-def test_linear_fwd(ops, M, N, K, ldpad):
+def test_linear_fwd(ops, gemm_mode, M, N, K, ldpad):
     xfull = rnd(M, K + ldpad, seed=1)
     x = xfull[:, :K]
     W, b = rnd(N, K, seed=2, scale=0.1), rnd(N, seed=3)
@@ -56,7 +66,7 @@ def test_linear_fwd(ops, M, N, K, ldpad):
 
 
 @pytest.mark.parametrize("M,N,K", [(130, 768, 192), (37, 64, 16), (70, 16, 4), (300, 64, 8)])
-def test_linear_gelu_fwd(ops, M, N, K):
+def test_linear_gelu_fwd(ops, gemm_mode, M, N, K):
     x, W, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.2), rnd(N, seed=3)
     pre_ref = (x.double() @ W.double().T + b.double()).requires_grad_(True)
     act_ref = F.gelu(pre_ref)
@@ -70,7 +80,7 @@ def test_linear_gelu_fwd(ops, M, N, K):
 
 
 @pytest.mark.parametrize("M,N,K,rmod", [(130, 192, 768, 130), (130, 96, 192, 65), (68, 4, 16, 17)])
-def test_linear_residual_fwd(ops, M, N, K, rmod):
+def test_linear_residual_fwd(ops, gemm_mode, M, N, K, rmod):
     x, W, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.1), rnd(N, seed=3)
     R = rnd(rmod, N, seed=4)
     ref = x.double() @ W.double().T + b.double() + R.double().repeat(M // rmod, 1)
@@ -96,9 +106,75 @@ def test_linear_bwd_input(ops, M, N, K):
     assert rel_err(dx3.cpu(), ref * gg.double()) < GEMM_TOL
 
 
+@pytest.mark.parametrize("M,N,K", [(130, 576, 192), (257, 192, 768), (33, 12, 24), (70, 12, 4), (300, 768, 192), (4160, 768, 192)])
+def test_linear_bwd_input_t(ops, gemm_mode, M, N, K):
+    """dX = dY W from the transposed weight copy (vsom_transpose_many + vsom_linear_bwd_input_t)."""
+    dy, W = rnd(M, N, seed=1), rnd(N, K, seed=2, scale=0.1)
+    ref = dy.double() @ W.double()
+    Wd = dev(W)
+    Wt = torch.empty(K, N, device=DEV)
+    table = torch.tensor([[0, 0, N, K]], dtype=torch.int64, device=DEV)
+    ops.transpose_many(Wd, Wt.view(-1), table, N, K)
+    assert torch.equal(Wt.cpu(), W.T.contiguous())
+    dx = torch.empty(M, K, device=DEV)
+    ops.linear_bwd_input_t(dev(dy), Wt, dx)
+    assert rel_err(dx.cpu(), ref) < GEMM_TOL
+    base = rnd(M, K, seed=5)
+    dx2 = dev(base).clone()
+    ops.linear_bwd_input_t(dev(dy), Wt, dx2, accumulate=True)
+    assert rel_err(dx2.cpu(), ref + base.double()) < GEMM_TOL
+    gg = rnd(M, K, seed=6)
+    dx3 = torch.empty(M, K, device=DEV)
+    ops.linear_bwd_input_t(dev(dy), Wt, dx3, gelu_grad=dev(gg))
+    assert rel_err(dx3.cpu(), ref * gg.double()) < GEMM_TOL
+
+
+def test_transpose_many_batched(ops):
+    shapes = [(192, 576), (37, 5), (768, 192), (4, 4), (1, 33)]
+    src = rnd(sum(r * c for r, c in shapes) + 64, seed=3)
+    rows, so, do = [], 0, 0
+    for r, c in shapes:
+        rows.append([so, do, r, c]); so += r * c; do += r * c
+    srcd, dst = dev(src), torch.zeros(do, device=DEV)
+    ops.transpose_many(srcd, dst, torch.tensor(rows, dtype=torch.int64, device=DEV), 768, 576)
+    for s0, d0, r, c in rows:
+        assert torch.equal(dst[d0:d0 + r * c].view(c, r).cpu(), src[s0:s0 + r * c].view(r, c).T)
+
+
+def test_split_bf16_wide_dynamic_range(ops):
+    """The split keeps fp32's exponent range and all 24 significand bits: operands spanning 60
+    orders of magnitude, and values with only low-order mantissa bits set, come out fp32-accurate."""
+    prev = ops.get_gemm_mode()
+    ops.set_gemm_mode(ops.GEMM_SPLIT_BF16)
+    try:
+        M, N, K = 96, 64, 128
+        x = rnd(M, K, seed=1) * torch.logspace(-30, 30, K).float()[None, :]
+        W = rnd(N, K, seed=2) * torch.logspace(25, -25, K).float()[None, :]
+        out = torch.empty(M, N, device=DEV)
+        ops.linear_fwd(dev(x), dev(W), None, out)
+        assert rel_err(out.cpu(), x.double() @ W.double().T) < GEMM_TOL
+        # 1 + 2^-23 and friends: the information sits in the last mantissa bits
+        x2 = (1.0 + torch.arange(M * K).view(M, K).float() % 7 * 2.0 ** -23)
+        W2 = torch.where(torch.arange(N * K).view(N, K) % 2 == 0, 1.0, -1.0).float()
+        ops.linear_fwd(dev(x2), dev(W2), None, out)
+        ref = x2.double() @ W2.double().T
+        assert float((out.cpu().double() - ref).abs().max()) < 2e-6      # |ref| ~ 1e-6 .. 1e-5: cancellation survives
+    finally:
+        ops.set_gemm_mode(prev)
+
+
+def test_gemm_mode_switch(ops):
+    prev = ops.get_gemm_mode()
+    assert prev in (ops.GEMM_F32, ops.GEMM_SPLIT_BF16)
+    from vit_som_amd._lib import VsomError
+    with pytest.raises(VsomError):
+        ops.set_gemm_mode(7)
+    assert ops.get_gemm_mode() == prev
+
+
 @pytest.mark.parametrize("M,N,K", [(1000, 576, 192), (4160, 192, 768), (70, 10, 24), (33, 4, 16), (650, 48, 96),
                                     (2080, 768, 192)])
-def test_linear_bwd_weight(ops, M, N, K):
+def test_linear_bwd_weight(ops, gemm_mode, M, N, K):
     dy, x = rnd(M, N, seed=1), rnd(M, K, seed=2)
     dW_ref, db_ref = dy.double().T @ x.double(), dy.double().sum(0)
     dW, db = torch.empty(N, K, device=DEV), torch.empty(N, device=DEV)
@@ -112,7 +188,7 @@ def test_linear_bwd_weight(ops, M, N, K):
 
 
 @pytest.mark.parametrize("B,C,S,p,E", [(6, 3, 32, 4, 192), (4, 1, 28, 2, 16), (3, 3, 8, 4, 24)])
-def test_patch_embed(ops, O, B, C, S, p, E):
+def test_patch_embed(ops, O, gemm_mode, B, C, S, p, E):
     n = (S // p) ** 2
     img = rnd(B, C, S, S, seed=1)
     W, b = rnd(E, C, p, p, seed=2, scale=0.2), rnd(E, seed=3)

@@ -24,6 +24,11 @@ SIGNATURES = {
                                            C.c_int, C.c_int, C.c_int, c_stream]),
     "vsom_linear_bwd_input": (C.c_int, [c_fp, C.c_long, c_fp, c_fp, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int,
                                         c_fp, c_stream]),
+    "vsom_linear_bwd_input_t": (C.c_int, [c_fp, C.c_long, c_fp, c_fp, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int,
+                                          c_fp, c_stream]),
+    "vsom_transpose_many": (C.c_int, [c_fp, c_fp, C.c_void_p, C.c_int, C.c_int, C.c_int, c_stream]),
+    "vsom_set_gemm_mode": (C.c_int, [C.c_int]),
+    "vsom_get_gemm_mode": (C.c_int, []),
     "vsom_linear_bwd_weight_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "vsom_linear_bwd_weight": (C.c_int, [c_fp, C.c_long, c_fp, C.c_long, c_fp, c_fp, C.c_int, C.c_int, C.c_int,
                                          c_fp, C.c_size_t, c_stream]),

@@ -175,6 +175,82 @@ __device__ __forceinline__ void store_ks(const StageRegs<COLS>& s, float* lds, i
         *reinterpret_cast<f32x4*>(lds + (p * KPP + t / TPR) * (COLS + 4) + ((t % TPR) << 2)) = s.v[p];
 }
 
+// ---- epilogue (shared by the exact-f32 and the split-bf16 kernels) ----------------------------
+// accumulator register v of a 32x32 tile holds row (v&3) + 8*(v>>2) + 4*h, column r: walk the
+// rows with pointer increments (no per-element index arithmetic); the rare output-row map
+// (patch embedding) takes the indexed path.  (m0, n0) = first row / column of this WAVE's tiles.
+template <int WM, int WN, int EPI>
+__device__ __forceinline__ void gemm_epilogue(const GemmP& g, const f32x16 (&acc)[WM][WN], int m0, int n0, int r, int h, int z) {
+    const bool rowmap = (EPI == EPI_BIAS_RES) && g.c_seg != 0;
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+            const int n = n0 + j * 32 + r;
+            if (n >= g.N) continue;
+            const int mb = m0 + i * 32 + 4 * h;
+            float bn = 0.f;
+            if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RES) bn = g.bias ? g.bias[n] : 0.f;
+            if constexpr (EPI == EPI_SLAB) {
+                float* dst = g.slab + (long)z * g.slab_stride + (long)mb * g.N + n;
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const int dm = (v & 3) + 8 * (v >> 2);
+                    if (mb + dm < g.M) dst[(long)dm * g.N] = acc[i][j][v];
+                }
+            } else if (rowmap) {
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const int m = mb + (v & 3) + 8 * (v >> 2);
+                    if (m >= g.M) continue;
+                    const long orow = (long)(m / g.c_seg) * g.c_stride + g.c_off + (m % g.c_seg);
+                    const long rr = (long)(m % g.r_mod) + g.r_off;
+                    g.C[orow * g.ldc + n] = acc[i][j][v] + bn + g.R[rr * g.ldr + n];
+                }
+            } else {
+                float* dst = g.C + (long)mb * g.ldc + n;
+                const float* rsrc = nullptr;
+                float* dst2 = nullptr;
+                if constexpr (EPI == EPI_ROWAXPY || EPI == EPI_GELU_BWD) rsrc = g.R + (long)mb * g.ldr + n;
+                if constexpr (EPI == EPI_BIAS_GELU) dst2 = g.C2 + (long)mb * g.ldc2 + n;
+                const bool plain_res = (EPI == EPI_BIAS_RES) && g.r_mod >= g.M && g.r_off == 0;
+                if constexpr (EPI == EPI_BIAS_RES) rsrc = g.R + (long)mb * g.ldr + n;
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const int dm = (v & 3) + 8 * (v >> 2);
+                    const int m = mb + dm;
+                    if (m >= g.M) continue;
+                    const float a = acc[i][j][v];
+                    float* d = dst + (long)dm * g.ldc;
+                    if constexpr (EPI == EPI_NONE) {
+                        float val = g.alpha * a;
+                        if (g.accumulate) val += *d;
+                        *d = val;
+                    } else if constexpr (EPI == EPI_BIAS) {
+                        *d = a + bn;
+                    } else if constexpr (EPI == EPI_BIAS_GELU) {
+                        float act, grad;
+                        gelu_erf_both(a + bn, act, grad);
+                        *d = grad;
+                        dst2[(long)dm * g.ldc2] = act;
+                    } else if constexpr (EPI == EPI_BIAS_RES) {
+                        const float rv = plain_res ? rsrc[(long)dm * g.ldr] : g.R[((long)(m % g.r_mod) + g.r_off) * g.ldr + n];
+                        *d = a + bn + rv;
+                    } else if constexpr (EPI == EPI_ROWAXPY) {
+                        float val = a + g.rowscale[m] * rsrc[(long)dm * g.ldr];
+                        if (g.accumulate) val += *d;
+                        *d = val;
+                    } else if constexpr (EPI == EPI_GELU_BWD) {
+                        float val = a * rsrc[(long)dm * g.ldr];
+                        if (g.accumulate) val += *d;
+                        *d = val;
+                    }
+                }
+            }
+        }
+    }
+}
+
 template <bool A_KC, bool B_KC, int WM, int WN, int WAVES_M, int WAVES_N, int EPI, bool FAST>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmP g) {
     constexpr int BM = WAVES_M * WM * 32;
@@ -304,81 +380,10 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmP g) {
         }
     }
 
-    // ---------------------------------------------------------------- epilogue
-    // accumulator register v of a 32x32 tile holds row (v&3) + 8*(v>>2) + 4*h, column r: walk the
-    // rows with pointer increments (no per-element index arithmetic); the rare output-row map
-    // (patch embedding) takes the indexed path.
     if constexpr (EPI == EPI_SLAB) {
         if (want_colsum && t < BM && bm0 + t < g.M) g.slab_bias[(long)z * g.slab_bias_stride + bm0 + t] = colsum;
     }
-    const bool rowmap = (EPI == EPI_BIAS_RES) && g.c_seg != 0;
-#pragma unroll
-    for (int i = 0; i < WM; ++i) {
-#pragma unroll
-        for (int j = 0; j < WN; ++j) {
-            const int n = bn0 + wn0 + j * 32 + r;
-            if (n >= g.N) continue;
-            const int mb = bm0 + wm0 + i * 32 + 4 * h;
-            float bn = 0.f;
-            if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RES) bn = g.bias ? g.bias[n] : 0.f;
-            if constexpr (EPI == EPI_SLAB) {
-                float* dst = g.slab + (long)z * g.slab_stride + (long)mb * g.N + n;
-#pragma unroll
-                for (int v = 0; v < 16; ++v) {
-                    const int dm = (v & 3) + 8 * (v >> 2);
-                    if (mb + dm < g.M) dst[(long)dm * g.N] = acc[i][j][v];
-                }
-            } else if (rowmap) {
-#pragma unroll
-                for (int v = 0; v < 16; ++v) {
-                    const int m = mb + (v & 3) + 8 * (v >> 2);
-                    if (m >= g.M) continue;
-                    const long orow = (long)(m / g.c_seg) * g.c_stride + g.c_off + (m % g.c_seg);
-                    const long rr = (long)(m % g.r_mod) + g.r_off;
-                    g.C[orow * g.ldc + n] = acc[i][j][v] + bn + g.R[rr * g.ldr + n];
-                }
-            } else {
-                float* dst = g.C + (long)mb * g.ldc + n;
-                const float* rsrc = nullptr;
-                float* dst2 = nullptr;
-                if constexpr (EPI == EPI_ROWAXPY || EPI == EPI_GELU_BWD) rsrc = g.R + (long)mb * g.ldr + n;
-                if constexpr (EPI == EPI_BIAS_GELU) dst2 = g.C2 + (long)mb * g.ldc2 + n;
-                const bool plain_res = (EPI == EPI_BIAS_RES) && g.r_mod >= g.M && g.r_off == 0;
-                if constexpr (EPI == EPI_BIAS_RES) rsrc = g.R + (long)mb * g.ldr + n;
-#pragma unroll
-                for (int v = 0; v < 16; ++v) {
-                    const int dm = (v & 3) + 8 * (v >> 2);
-                    const int m = mb + dm;
-                    if (m >= g.M) continue;
-                    const float a = acc[i][j][v];
-                    float* d = dst + (long)dm * g.ldc;
-                    if constexpr (EPI == EPI_NONE) {
-                        float val = g.alpha * a;
-                        if (g.accumulate) val += *d;
-                        *d = val;
-                    } else if constexpr (EPI == EPI_BIAS) {
-                        *d = a + bn;
-                    } else if constexpr (EPI == EPI_BIAS_GELU) {
-                        float act, grad;
-                        gelu_erf_both(a + bn, act, grad);
-                        *d = grad;
-                        dst2[(long)dm * g.ldc2] = act;
-                    } else if constexpr (EPI == EPI_BIAS_RES) {
-                        const float rv = plain_res ? rsrc[(long)dm * g.ldr] : g.R[((long)(m % g.r_mod) + g.r_off) * g.ldr + n];
-                        *d = a + bn + rv;
-                    } else if constexpr (EPI == EPI_ROWAXPY) {
-                        float val = a + g.rowscale[m] * rsrc[(long)dm * g.ldr];
-                        if (g.accumulate) val += *d;
-                        *d = val;
-                    } else if constexpr (EPI == EPI_GELU_BWD) {
-                        float val = a * rsrc[(long)dm * g.ldr];
-                        if (g.accumulate) val += *d;
-                        *d = val;
-                    }
-                }
-            }
-        }
-    }
+    gemm_epilogue<WM, WN, EPI>(g, acc, bm0 + wm0, bn0 + wn0, r, h, z);
 }
 
 // host-side launcher (gemm_f32.hip)

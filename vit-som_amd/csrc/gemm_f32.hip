@@ -1,7 +1,11 @@
 // GEMM launcher + the nn.Linear-shaped C-ABI entries built on it.
 #include "gemm_f32.h"
+#include "gemm_x6.h"
+
+#include <atomic>
 
 #include <stdarg.h>
+#include <stdlib.h>
 
 namespace vsom {
 
@@ -13,6 +17,11 @@ void set_error(const char* fmt, ...) {
     va_end(ap);
 }
 const char* last_error() { return g_err; }
+
+// Arithmetic of the nn.Linear-shaped ("NT") GEMMs: VSOM_GEMM_SPLIT_BF16 (default) or VSOM_GEMM_F32.
+// The BMU distance GEMM (EPI_SLAB) always runs the exact-f32 engine.
+static std::atomic<int> g_gemm_mode{VSOM_GEMM_SPLIT_BF16};
+int gemm_mode() { return g_gemm_mode.load(std::memory_order_relaxed); }
 
 // One tile configuration: 128 x 64 (4 waves, each 32 x 64 = two 32x32 accumulators).  Measured
 // against 128 x 128 on every GEMM shape of the step (and 4096^3): faster everywhere -- three
@@ -41,11 +50,35 @@ static int launch_t(GemmP& g, int splits, hipStream_t stream) {
     const bool fast = g.a_vec && g.b_vec && (a_cols % 4 == 0) && (b_cols % 4 == 0) && ab < 0xFFFF0000L && bb < 0xFFFF0000L;
     g.a_bytes = (unsigned)ab; g.b_bytes = (unsigned)bb;
     g.n_major = bb > ab;        // share the larger operand's panel between neighbouring workgroups
+    if constexpr (!A_KC && !B_KC && EPI == EPI_SLAB) {
+        if (fast && gemm_mode() == VSOM_GEMM_SPLIT_BF16) {
+            if (BM == 64) hipLaunchKernelGGL((gemm_x6_kernel<false, 1, 1, 2, 2, EPI>), grid, block, 0, stream, g);
+            else hipLaunchKernelGGL((gemm_x6_kernel<false, 1, 2, 4, 1, EPI>), grid, block, 0, stream, g);
+            VSOM_LAUNCH_CHECK("gemm_x6_kernel");
+        }
+    }
     if constexpr (!A_KC && !B_KC) {
         if (BM == 64) {
             if (fast) hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, 1, 1, 2, 2, EPI, true>), grid, block, 0, stream, g);
             else hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, 1, 1, 2, 2, EPI, false>), grid, block, 0, stream, g);
             VSOM_LAUNCH_CHECK("gemm_f32_kernel");
+        }
+    }
+    if constexpr (A_KC && B_KC && EPI != EPI_SLAB) {
+        if (fast && gemm_mode() == VSOM_GEMM_SPLIT_BF16) {
+            // 128 x 64 or 64 x 64 tiles: whichever wastes less of the last round of workgroups
+            // (256 CUs; e.g. the step's 33280-row GEMMs make 260 row tiles of 128 -- a 4-tile tail
+            // that costs a whole extra round); the small tile is charged 2 % for its extra staging.
+            auto rounds = [](long n) { return (double)((n + 255) / 256); };
+            const double c128 = rounds((long)cdiv(g.M, 128) * cdiv(g.N, 64) * splits) * 2.0;
+            const double c64 = rounds((long)cdiv(g.M, 64) * cdiv(g.N, 64) * splits) * 1.02;
+            if (c64 < c128) {
+                dim3 grid64(cdiv(g.M, 64) * cdiv(g.N, 64) * splits, 1, 1);
+                hipLaunchKernelGGL((gemm_x6_kernel<true, 1, 1, 2, 2, EPI>), grid64, block, 0, stream, g);
+                VSOM_LAUNCH_CHECK("gemm_x6_kernel");
+            }
+            hipLaunchKernelGGL((gemm_x6_kernel<true, 1, 2, 4, 1, EPI>), grid, block, 0, stream, g);
+            VSOM_LAUNCH_CHECK("gemm_x6_kernel");
         }
     }
     if (fast)
@@ -73,6 +106,8 @@ int launch_gemm(bool a_kc, bool b_kc, int epi, GemmP g, int splits, hipStream_t 
             case EPI_BIAS_GELU: return launch_t<true, true, EPI_BIAS_GELU>(g, splits, stream);
             case EPI_BIAS_RES: return launch_t<true, true, EPI_BIAS_RES>(g, splits, stream);
             case EPI_SLAB: return launch_t<true, true, EPI_SLAB>(g, splits, stream);
+            case EPI_NONE: return launch_t<true, true, EPI_NONE>(g, splits, stream);
+            case EPI_GELU_BWD: return launch_t<true, true, EPI_GELU_BWD>(g, splits, stream);
         }
     } else if (a_kc && !b_kc) {
         switch (epi) {
@@ -299,6 +334,28 @@ int vsom_linear_bwd_input(const float* dY, long lddy, const float* W, float* dX,
     }
     return launch_gemm(true, false, EPI_NONE, g, 1, stream);
 }
+
+int vsom_linear_bwd_input_t(const float* dY, long lddy, const float* Wt, float* dX, long lddx, int M, int N, int K,
+                            int accumulate, const float* gelu_grad, vsom_stream_t stream) {
+    VSOM_REQUIRE(dY && Wt && dX, VSOM_EINVAL, "linear_bwd_input_t: null pointer");
+    VSOM_REQUIRE(lddy >= N && lddx >= K, VSOM_EINVAL, "linear_bwd_input_t: leading dimension too small");
+    // dX[M,K] = dY[M,N] * Wt[K,N]^T: both operands contiguous along the reduction (N)
+    GemmP g = {};
+    g.A = dY; g.lda = lddy; g.B = Wt; g.ldb = N; g.C = dX; g.ldc = lddx;
+    g.M = M; g.N = K; g.K = N; g.alpha = 1.f; g.accumulate = accumulate;
+    if (gelu_grad) {
+        g.R = gelu_grad; g.ldr = K;
+        return launch_gemm(true, true, EPI_GELU_BWD, g, 1, stream);
+    }
+    return launch_gemm(true, true, EPI_NONE, g, 1, stream);
+}
+
+int vsom_set_gemm_mode(int mode) {
+    VSOM_REQUIRE(mode == VSOM_GEMM_F32 || mode == VSOM_GEMM_SPLIT_BF16, VSOM_EINVAL, "set_gemm_mode: unknown mode %d", mode);
+    g_gemm_mode.store(mode, std::memory_order_relaxed);
+    return VSOM_OK;
+}
+int vsom_get_gemm_mode(void) { return gemm_mode(); }
 
 size_t vsom_linear_bwd_weight_workspace_bytes(int M, int N, int K) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;

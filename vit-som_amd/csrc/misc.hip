@@ -146,6 +146,32 @@ __global__ __launch_bounds__(256) void fill_kernel(float* __restrict__ p, long n
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) p[i] = value;
 }
 
+// batched 32x32-tile transpose through LDS; blockIdx.y = tensor, blockIdx.x = tile (surplus tiles exit)
+__global__ __launch_bounds__(256) void transpose_many_kernel(const float* __restrict__ src_base, float* __restrict__ dst_base,
+                                                             const long long* __restrict__ table) {
+    __shared__ float tile[32][33];
+    const long long* e = table + 4 * (long)blockIdx.y;
+    const long so = e[0], dof = e[1];
+    const int rows = (int)e[2], cols = (int)e[3];
+    const int tc = (cols + 31) >> 5, tr = (rows + 31) >> 5;
+    if ((int)blockIdx.x >= tc * tr) return;
+    const int r0 = ((int)blockIdx.x / tc) << 5, c0 = ((int)blockIdx.x % tc) << 5;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const float* src = src_base + so;
+    float* dst = dst_base + dof;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = r0 + ty + 8 * i, c = c0 + tx;
+        if (r < rows && c < cols) tile[ty + 8 * i][tx] = src[(long)r * cols + c];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = c0 + ty + 8 * i, r = r0 + tx;
+        if (r < rows && c < cols) dst[(long)c * rows + r] = tile[tx][ty + 8 * i];
+    }
+}
+
 static int grid_for(long n, int per_block, int cap) {
     long b = (n + per_block - 1) / per_block;
     if (b > cap) b = cap;
@@ -164,6 +190,16 @@ int vsom_fill(float* p, long n, float value, vsom_stream_t stream) {
     if (n == 0) return VSOM_OK;
     hipLaunchKernelGGL(fill_kernel, dim3(grid_for(n, 1024, 4096)), dim3(256), 0, stream, p, n, value);
     VSOM_LAUNCH_CHECK("fill_kernel");
+}
+
+int vsom_transpose_many(const float* src_base, float* dst_base, const long long* table, int count, int max_rows,
+                        int max_cols, vsom_stream_t stream) {
+    VSOM_REQUIRE(src_base && dst_base && table && count >= 0 && max_rows > 0 && max_cols > 0, VSOM_EINVAL, "transpose_many: bad arguments");
+    if (count == 0) return VSOM_OK;
+    VSOM_REQUIRE(count <= 65535, VSOM_EINVAL, "transpose_many: more than 65535 tensors");
+    dim3 grid(cdiv(max_rows, 32) * cdiv(max_cols, 32), count);
+    hipLaunchKernelGGL(transpose_many_kernel, grid, dim3(256), 0, stream, src_base, dst_base, table);
+    VSOM_LAUNCH_CHECK("transpose_many_kernel");
 }
 
 int vsom_patch_embed_fwd(const float* img, const float* Wpe, const float* bpe, const float* pos,

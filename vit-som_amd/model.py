@@ -302,7 +302,15 @@ class ViTAutoencoder(nn.Module):
         return xe[:, 0].clone(), xe[:, 1:].clone(), recon
 
     # -- backward -----------------------------------------------------------------------------
-    def _block_bwd(self, blk: Block, L: _Acts, x_in, gout, a: _Acts, G, prefix: str, bufs):
+    @staticmethod
+    def _dx(WT, dy, weight, dx, **kw):
+        """dX = dY W: from the transposed weight copy when the owner keeps one (NT kernel family)."""
+        wt = WT(weight) if WT is not None else None
+        if wt is not None:
+            return ops.linear_bwd_input_t(dy, wt, dx, **kw)
+        return ops.linear_bwd_input(dy, weight, dx, **kw)
+
+    def _block_bwd(self, blk: Block, L: _Acts, x_in, gout, a: _Acts, G, prefix: str, bufs, WT=None):
         """gout: gradient w.r.t. the block output [T,dim]; returns gradient w.r.t. x_in (in bufs)."""
         T, dim, hid = a.T, blk.dim, blk.hidden
         g1, g0 = bufs
@@ -310,16 +318,16 @@ class ViTAutoencoder(nn.Module):
         da = a.da[:T * dim].view(T, dim)
         dqkv = a.dqkv[:T * 3 * dim].view(T, 3 * dim)
         ops.linear_bwd_weight(gout, L.hact, G(f"{prefix}.mlp.2.weight"), G(f"{prefix}.mlp.2.bias"))
-        ops.linear_bwd_input(gout, blk.mlp["2"].weight, dh, gelu_grad=L.hpre)
+        self._dx(WT, gout, blk.mlp["2"].weight, dh, gelu_grad=L.hpre)
         ops.linear_bwd_weight(dh, L.a2, G(f"{prefix}.mlp.0.weight"), G(f"{prefix}.mlp.0.bias"))
-        ops.linear_bwd_input(dh, blk.mlp["0"].weight, da)
+        self._dx(WT, dh, blk.mlp["0"].weight, da)
         ops.layernorm_bwd(da, L.x1, L.mean2, L.rstd2, blk.norm2.weight, gout, g1, G(f"{prefix}.norm2.weight"),
                           G(f"{prefix}.norm2.bias"))
         ops.linear_bwd_weight(g1, L.ao, G(f"{prefix}.attn.proj.weight"), G(f"{prefix}.attn.proj.bias"))
-        ops.linear_bwd_input(g1, blk.attn.proj.weight, da)
+        self._dx(WT, g1, blk.attn.proj.weight, da)
         ops.attention_bwd(L.qkv, L.ao, da, L.lse, dqkv, a.delta, a.B, a.N, blk.heads, dim // blk.heads)
         ops.linear_bwd_weight(dqkv, L.a1, G(f"{prefix}.attn.qkv.weight"), G(f"{prefix}.attn.qkv.bias"))
-        ops.linear_bwd_input(dqkv, blk.attn.qkv.weight, da)
+        self._dx(WT, dqkv, blk.attn.qkv.weight, da)
         ops.layernorm_bwd(da, x_in, L.mean1, L.rstd1, blk.norm1.weight, g1, g0, G(f"{prefix}.norm1.weight"),
                           G(f"{prefix}.norm1.bias"))
         return g0
@@ -327,26 +335,26 @@ class ViTAutoencoder(nn.Module):
     def _views(self, a: _Acts, dim: int):
         return [b[:a.T * dim].view(a.T, dim) for b in a.g]
 
-    def _decoder_bwd(self, a: _Acts, G):
+    def _decoder_bwd(self, a: _Acts, G, WT=None):
         """a.dpred holds dL/dpred; writes decoder grads and dL/d(xe) into a.d_xe (overwrite)."""
         DE = self.decoder_embed_dim
         gA, gB, gC = self._views(a, DE)
         ops.linear_bwd_weight(a.dpred, a.dn, G("decoder_pred.weight"), G("decoder_pred.bias"))
         dn_grad = a.da[:a.T * DE].view(a.T, DE)
-        ops.linear_bwd_input(a.dpred, self.decoder_pred.weight, dn_grad)
+        self._dx(WT, a.dpred, self.decoder_pred.weight, dn_grad)
         x_last = a.dec[-1].x2 if a.dec else a.dec0
         ops.layernorm_bwd(dn_grad, x_last, a.mean_d, a.rstd_d, self.decoder_norm.weight, None, gA,
                           G("decoder_norm.weight"), G("decoder_norm.bias"))
         gout, free = gA, [gB, gC]
         for i in reversed(range(len(self.decoder_blocks))):
             x_in = a.dec[i - 1].x2 if i > 0 else a.dec0
-            g0 = self._block_bwd(self.decoder_blocks[i], a.dec[i], x_in, gout, a, G, f"decoder_blocks.{i}", free)
+            g0 = self._block_bwd(self.decoder_blocks[i], a.dec[i], x_in, gout, a, G, f"decoder_blocks.{i}", free, WT)
             free = [b for b in (gA, gB, gC) if b is not g0]
             gout = g0
         ops.linear_bwd_weight(gout, a.xe, G("decoder_embed.weight"), G("decoder_embed.bias"))
-        ops.linear_bwd_input(gout, self.decoder_embed.weight, a.d_xe)
+        self._dx(WT, gout, self.decoder_embed.weight, a.d_xe)
 
-    def _encoder_bwd(self, a: _Acts, G):
+    def _encoder_bwd(self, a: _Acts, G, WT=None):
         """a.d_xe holds dL/d(xe); writes every encoder gradient."""
         E = self.embed_dim
         gA, gB, gC = self._views(a, E)
@@ -355,7 +363,7 @@ class ViTAutoencoder(nn.Module):
         gout, free = gA, [gB, gC]
         for i in reversed(range(len(self.blocks))):
             x_in = a.enc[i - 1].x2 if i > 0 else a.tok0
-            g0 = self._block_bwd(self.blocks[i], a.enc[i], x_in, gout, a, G, f"blocks.{i}", free)
+            g0 = self._block_bwd(self.blocks[i], a.enc[i], x_in, gout, a, G, f"blocks.{i}", free, WT)
             free = [b for b in (gA, gB, gC) if b is not g0]
             gout = g0
         p = self.patch_embed.patch_size[0]
@@ -686,6 +694,35 @@ class ViTSOM(_Base):
         self.arena = arena
         self._anchor = None
         self._grad_views = {n: arena.g(n) for n, _ in named}
+        self._build_weight_transposes()
+
+    def _build_weight_transposes(self):
+        """Transposed copies W^T of the ViT Linear weights whose input gradient is needed, so that
+        dX = dY W runs on the forward's kernel family (both operands contiguous along the reduction).
+        One flat buffer + a device table; refreshed by ONE batched transpose per backward pass."""
+        arena, dev = self.arena, self.arena.device
+        rows, views, off = [], {}, 0
+        for n, p in self._named_trainable():
+            if not (n.startswith("vit.") and p.ndim == 2 and n.endswith(".weight")) or "patch_embed" in n:
+                continue
+            N, K = p.shape
+            if N % 4 or K % 4:
+                continue
+            src = (arena.p(n).data_ptr() - arena.params.data_ptr()) // 4
+            rows.append((src, off, N, K))
+            views[arena.p(n).data_ptr()] = (off, K, N)
+            off += -(-N * K // 64) * 64
+        self._wt_flat = torch.empty(max(off, 1), dtype=torch.float32, device=dev)
+        self._wt_table = torch.tensor(rows, dtype=torch.int64, device=dev).view(-1, 4) if rows else None
+        self._wt_views = {k: self._wt_flat[o:o + a * b].view(a, b) for k, (o, a, b) in views.items()}
+        self._wt_max = (max(r[2] for r in rows), max(r[3] for r in rows)) if rows else (1, 1)
+
+    def _refresh_weight_transposes(self):
+        if self._wt_table is not None and self._wt_flat.is_cuda:
+            ops.transpose_many(self.arena.params, self._wt_flat, self._wt_table, *self._wt_max)
+
+    def _WT(self, weight):
+        return self._wt_views.get(weight.data_ptr())
 
     def _apply(self, fn, *args, **kwargs):
         super()._apply(fn, *args, **kwargs)
@@ -822,6 +859,7 @@ class ViTSOM(_Base):
         x, a, s = self._ctx
         self._grads_reduced = False
         Gv = self._G("vit.")
+        self._refresh_weight_transposes()
         if self.classification:
             ops.fill(a.d_xe, 0.0)
             # decoder is unused by the classification loss: its gradients are exactly zero
@@ -831,7 +869,7 @@ class ViTSOM(_Base):
                                   self._grad_views["cls_head.bias"])
             ops.linear_bwd_input(a.dlogits, self.cls_head.weight, self._cls_view(a.d_xe, a), accumulate=True)
         else:
-            self.vit._decoder_bwd(a, Gv)
+            self.vit._decoder_bwd(a, Gv, self._WT)
         X = self._som_input(a)
         E, N = self.vit.embed_dim, a.N
         if self.use_reduced:
@@ -840,7 +878,7 @@ class ViTSOM(_Base):
             gX = torch.as_strided(a.d_xe, (a.B, (N - 1) * E), (N * E, 1), a.d_xe.storage_offset() + E)
         ops.som_bwd(X, self.som_layer.prototypes, s.coef, s.row_dot, s.col_dot, self._grad_views["som_layer.prototypes"],
                     gX, accumulate_gx=True)
-        self.vit._encoder_bwd(a, Gv)
+        self.vit._encoder_bwd(a, Gv, self._WT)
 
     # -- data-parallel exchange ----------------------------------------------------------------
     def allreduce_gradients(self):

@@ -107,6 +107,40 @@ def linear_bwd_input(dy, W, dx, accumulate=False, gelu_grad=None):
     return dx
 
 
+def linear_bwd_input_t(dy, Wt, dx, accumulate=False, gelu_grad=None):
+    """dX (+)= dY * W from the transposed copy Wt[K,N] (see transpose_many)."""
+    M, N = dy.shape
+    K = Wt.shape[0]
+    _f32(dy, "dy"); _f32(Wt, "Wt"); _f32(dx, "dx")
+    assert Wt.shape[1] == N and Wt.is_contiguous() and dx.shape == (M, K)
+    if gelu_grad is not None:
+        assert gelu_grad.is_contiguous() and gelu_grad.shape == (M, K)
+    check(lib.vsom_linear_bwd_input_t(ptr(dy), _rows(dy), ptr(Wt), ptr(dx), _rows(dx), M, N, K, int(accumulate),
+                                      ptr(gelu_grad), stream()), "vsom_linear_bwd_input_t")
+    return dx
+
+
+def transpose_many(src_base, dst_base, table, max_rows, max_cols):
+    """table: device int64 [count,4] rows {src_off, dst_off, rows, cols} (offsets in floats)."""
+    _f32(src_base, "src_base"); _f32(dst_base, "dst_base")
+    assert table.dtype == torch.int64 and table.is_contiguous() and table.ndim == 2 and table.shape[1] == 4
+    assert table.device == src_base.device == dst_base.device
+    check(lib.vsom_transpose_many(ptr(src_base), ptr(dst_base), table.data_ptr(), table.shape[0], int(max_rows),
+                                  int(max_cols), stream()), "vsom_transpose_many")
+    return dst_base
+
+
+GEMM_F32, GEMM_SPLIT_BF16 = 0, 1
+
+
+def set_gemm_mode(mode: int):
+    check(lib.vsom_set_gemm_mode(int(mode)), "vsom_set_gemm_mode")
+
+
+def get_gemm_mode() -> int:
+    return int(lib.vsom_get_gemm_mode())
+
+
 def linear_bwd_weight(dy, x, dW, db):
     M, N = dy.shape
     K = x.shape[1]
