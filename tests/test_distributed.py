@@ -39,11 +39,21 @@ def _cpu_worker(rank, world, port, out):
     # prototypes' accumulator is part of the same buffer
     off, n, _ = m.arena.offsets["som_layer.prototypes"]
     ok_proto = bool(torch.equal(m._grad_views["som_layer.prototypes"].flatten(), expect[off:off + n]))
+    # overlapped form: the prototype slice starts early (async), the remaining pieces follow
+    m.arena.grads.copy_(torch.arange(m.arena.numel, dtype=torch.float32) * (rank + 1))
+    m._grads_reduced = False
+    m._start_prototype_allreduce()
+    started = m._early is not None
+    m.allreduce_gradients()
+    ok_overlap = started and bool(torch.equal(m.arena.grads, expect)) and m._early is None
+    m.allreduce_gradients()                                   # idempotent until the next backward
+    ok_overlap = ok_overlap and bool(torch.equal(m.arena.grads, expect))
     hp = cfg["hyperparameters"]
     ok_T = abs(m.som_layer.total_iterations() - (int(z["n_train"]) / (hp["batch_size"] * world)) * hp["total_epochs"]) < 1e-9
     if rank == 0:
-        torch.save({"same_init": same_init, "ok_sum": ok_sum, "ok_proto": ok_proto, "ok_T": ok_T}, out)
-    res = torch.tensor([float(same_init and ok_sum and ok_proto and ok_T)])
+        torch.save({"same_init": same_init, "ok_sum": ok_sum, "ok_proto": ok_proto, "ok_T": ok_T,
+                    "ok_overlap": ok_overlap}, out)
+    res = torch.tensor([float(same_init and ok_sum and ok_proto and ok_T and ok_overlap)])
     dist.all_reduce(res, op=dist.ReduceOp.MIN)
     assert float(res) == 1.0
     dist.destroy_process_group()
@@ -53,7 +63,7 @@ def test_gloo_world2_exchange_and_schedules(tmp_path):
     out = str(tmp_path / "r0.pt")
     mp.spawn(_cpu_worker, args=(2, _free_port(), out), nprocs=2, join=True)
     r = torch.load(out)
-    assert r == {"same_init": True, "ok_sum": True, "ok_proto": True, "ok_T": True}
+    assert r == {"same_init": True, "ok_sum": True, "ok_proto": True, "ok_T": True, "ok_overlap": True}
 
 
 def _gpu_worker(rank, world, port, out):

@@ -32,14 +32,33 @@ __global__ __launch_bounds__(256) void cls_rows_kernel(const float* __restrict__
     tokens[b * Ntok * E + e] = cls_token[e] + pos[e];
 }
 
-// dcls[e] = sum_b dtokens[b, 0, e]   (fixed order)
+// dcls[e] = sum_b dtokens[b, 0, e]   (fixed order).  A workgroup owns 32 columns; its 8 row groups
+// each sum every 8th image with 4 independent accumulators and are combined through LDS in order.
 __global__ __launch_bounds__(256) void cls_grad_kernel(const float* __restrict__ dtokens, float* __restrict__ dcls,
                                                        int B, int Ntok, int E) {
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= E) return;
-    float s = 0.f;
-    for (int b = 0; b < B; ++b) s += dtokens[(long)b * Ntok * E + e];
-    dcls[e] = s;
+    __shared__ float part[8][32];
+    const int c = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const int e = blockIdx.x * 32 + c;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (e < E) {
+        const long stride = (long)Ntok * E;
+        int b = rg;
+        for (; b + 24 < B; b += 32) {
+            s0 += dtokens[(long)b * stride + e];
+            s1 += dtokens[(long)(b + 8) * stride + e];
+            s2 += dtokens[(long)(b + 16) * stride + e];
+            s3 += dtokens[(long)(b + 24) * stride + e];
+        }
+        for (; b < B; b += 8) s0 += dtokens[(long)b * stride + e];
+    }
+    part[rg][c] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (rg == 0 && e < E) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s += part[i][c];
+        dcls[e] = s;
+    }
 }
 
 // ------------------------------------------------------------------ L1 + unpatchify
@@ -241,7 +260,7 @@ int vsom_patch_embed_bwd(const float* dtokens, const float* xp_ws, float* dWpe, 
     const int M = B * n;
     int rc = linear_bwd_weight_impl(dtokens, E, xp_ws, pd, dWpe, dbpe, M, E, pd, n, Ntok, 1, ws, ws_bytes, stream);
     if (rc) return rc;
-    hipLaunchKernelGGL(cls_grad_kernel, dim3(cdiv(E, 256)), dim3(256), 0, stream, dtokens, dcls_token, B, Ntok, E);
+    hipLaunchKernelGGL(cls_grad_kernel, dim3(cdiv(E, 32)), dim3(256), 0, stream, dtokens, dcls_token, B, Ntok, E);
     VSOM_LAUNCH_CHECK("cls_grad_kernel");
 }
 

@@ -111,25 +111,40 @@ __global__ __launch_bounds__(256) void som_neigh_row_kernel(const float* __restr
         if (row_dot) row_dot[i] = c * (euclid ? 1.0f : rx * rx) * ((s2[0] + s2[1]) + (s2[2] + s2[3]));
     }
 }
-// thread per prototype column k, fixed-order loop over the B sample rows
+// col_dot[k] = c rw^2 sum_i term(i,k).  A workgroup owns 32 prototype columns; its 8 row groups each
+// take every 8th sample row (two independent accumulators) and are combined through LDS in a
+// fixed order -> bitwise reproducible.
 __global__ __launch_bounds__(256) void som_neigh_col_kernel(const float* __restrict__ dist,
                                                             const int64_t* __restrict__ bmu,
                                                             const float* __restrict__ grid, float inv_2T2,
                                                             const float* __restrict__ inv_nw, float c,
                                                             float* __restrict__ col_dot, int B, int K, int euclid) {
-    const int k = blockIdx.x * 256 + threadIdx.x;
-    if (k >= K) return;
-    const float gy = grid[2 * k], gx = grid[2 * k + 1];
-    float s = 0.f;
-    for (int i = 0; i < B; ++i) {
-        const int64_t b = bmu[i];
-        const float dy = gy - grid[2 * b], dx = gx - grid[2 * b + 1];
-        const float h = expf(-(dy * dy + dx * dx) * inv_2T2);
-        const float d = dist[(long)i * K + k];
-        s += euclid ? ((d > 0.f) ? h / d : 0.f) : h * (1.0f - d);
+    __shared__ float part[8][32];
+    const int cidx = threadIdx.x & 31, rg = threadIdx.x >> 5;
+    const int k = blockIdx.x * 32 + cidx;
+    float s0 = 0.f, s1 = 0.f;
+    if (k < K) {
+        const float gy = grid[2 * k], gx = grid[2 * k + 1];
+        auto term = [&](int i) {
+            const int64_t b = bmu[i];
+            const float dy = gy - grid[2 * b], dx = gx - grid[2 * b + 1];
+            const float h = expf(-(dy * dy + dx * dx) * inv_2T2);
+            const float d = dist[(long)i * K + k];
+            return euclid ? ((d > 0.f) ? h / d : 0.f) : h * (1.0f - d);
+        };
+        int i = rg;
+        for (; i + 8 < B; i += 16) { s0 += term(i); s1 += term(i + 8); }
+        if (i < B) s0 += term(i);
     }
-    const float rw = euclid ? 1.0f : inv_nw[k];
-    col_dot[k] = c * rw * rw * s;
+    part[rg][cidx] = s0 + s1;
+    __syncthreads();
+    if (rg == 0 && k < K) {
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += part[j][cidx];
+        const float rw = euclid ? 1.0f : inv_nw[k];
+        col_dot[k] = c * rw * rw * s;
+    }
 }
 // deterministic sum of n partials into out[0] (single workgroup)
 __global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restrict__ part, int n,
@@ -243,7 +258,7 @@ int vsom_som_neigh_loss(const float* dist, const int64_t* bmu, const float* grid
     rc = sum_partials(part, B, loss_sum, stream);
     if (rc) return rc;
     if (bwd) {
-        hipLaunchKernelGGL(som_neigh_col_kernel, dim3(cdiv(K, 256)), dim3(256), 0, stream, dist, bmu, grid, inv_2T2,
+        hipLaunchKernelGGL(som_neigh_col_kernel, dim3(cdiv(K, 32)), dim3(256), 0, stream, dist, bmu, grid, inv_2T2,
                            inv_nw, grad_scale, col_dot, B, K, euclid);
         rc = hip_status(hipGetLastError(), "som_neigh_col_kernel");
     }

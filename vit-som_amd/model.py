@@ -858,6 +858,7 @@ class ViTSOM(_Base):
         """All backward kernels; overwrites the whole gradient arena (no accumulation)."""
         x, a, s = self._ctx
         self._grads_reduced = False
+        self._early = None
         Gv = self._G("vit.")
         self._refresh_weight_transposes()
         if self.classification:
@@ -878,24 +879,56 @@ class ViTSOM(_Base):
             gX = torch.as_strided(a.d_xe, (a.B, (N - 1) * E), (N * E, 1), a.d_xe.storage_offset() + E)
         ops.som_bwd(X, self.som_layer.prototypes, s.coef, s.row_dot, s.col_dot, self._grad_views["som_layer.prototypes"],
                     gX, accumulate_gx=True)
+        self._start_prototype_allreduce()
         self.vit._encoder_bwd(a, Gv, self._WT)
 
     # -- data-parallel exchange ----------------------------------------------------------------
+    def _overlap_enabled(self) -> bool:
+        import os
+        return self.world_size > 1 and os.environ.get("VSOM_OVERLAP_ALLREDUCE", "1") != "0"
+
+    def _start_prototype_allreduce(self):
+        """Called inside the backward pass right after the SOM backward: the [K, L] prototype
+        gradient (the bulk of the exchange: 79 MB of 100 MB at CIFAR shapes) is final, while the
+        whole encoder backward is still to run -- start its all-reduce now (RCCL runs it on its own
+        stream, ordered after the kernels already queued) and let it finish under those kernels."""
+        self._early = None
+        if not self._overlap_enabled():
+            return
+        import torch.distributed as dist
+        g = self.arena.grads
+        off, n, _ = self.arena.offsets["som_layer.prototypes"]
+        piece = g[off:off + n]
+        if g.is_cuda and dist.get_backend() == "gloo":
+            return                                   # CPU rehearsal backend: exchanged with the rest, staged through the host
+        self._early = (off, n, dist.all_reduce(piece, op=dist.ReduceOp.SUM, async_op=True))
+
     def allreduce_gradients(self):
-        """Sum the whole gradient arena (ViT grads + prototype accumulators) across ranks with ONE
-        all-reduce (RCCL over xGMI under the "nccl" backend); AdamW divides by world_size.  Under the
-        gloo backend (CPU rehearsal of the N > 1 path) device tensors are staged through the host."""
+        """Sum the gradient arena (ViT grads + prototype accumulators) across ranks (RCCL over xGMI
+        under the "nccl" backend); AdamW divides by world_size.  The prototype slice may already be
+        in flight (see _start_prototype_allreduce); the rest goes in one call per contiguous piece.
+        Under the gloo backend (CPU rehearsal of the N > 1 path) device tensors are staged through
+        the host."""
         if self.world_size <= 1 or self._grads_reduced:
             return
         self._grads_reduced = True            # idempotent until the next backward pass
         import torch.distributed as dist
         g = self.arena.grads
+        early, self._early = getattr(self, "_early", None), None
         if g.is_cuda and dist.get_backend() == "gloo":
             host = g.cpu()
             dist.all_reduce(host, op=dist.ReduceOp.SUM)
             g.copy_(host)
-        else:
+            return
+        if early is None:
             dist.all_reduce(g, op=dist.ReduceOp.SUM)
+            return
+        off, n, work = early
+        if off > 0:
+            dist.all_reduce(g[:off], op=dist.ReduceOp.SUM)
+        if off + n < g.numel():
+            dist.all_reduce(g[off + n:], op=dist.ReduceOp.SUM)
+        work.wait()                            # the consumer stream now waits for the early piece
 
     # -- reference API ---------------------------------------------------------------------------
     def _schedules_for_step(self):
