@@ -50,10 +50,10 @@ static int launch_t(GemmP& g, int splits, hipStream_t stream) {
     const bool fast = g.a_vec && g.b_vec && (a_cols % 4 == 0) && (b_cols % 4 == 0) && ab < 0xFFFF0000L && bb < 0xFFFF0000L;
     g.a_bytes = (unsigned)ab; g.b_bytes = (unsigned)bb;
     g.n_major = bb > ab;        // share the larger operand's panel between neighbouring workgroups
-    if constexpr (!A_KC && !B_KC && EPI == EPI_SLAB) {
+    if constexpr (!A_KC && !B_KC && (EPI == EPI_SLAB || EPI == EPI_ROWAXPY)) {
         if (fast && gemm_mode() == VSOM_GEMM_SPLIT_BF16) {
-            if (BM == 64) hipLaunchKernelGGL((gemm_x6_kernel<false, 1, 1, 2, 2, EPI>), grid, block, 0, stream, g);
-            else hipLaunchKernelGGL((gemm_x6_kernel<false, 1, 2, 4, 1, EPI>), grid, block, 0, stream, g);
+            if (BM == 64) hipLaunchKernelGGL((gemm_x6_kernel<false, false, 1, 1, 2, 2, EPI>), grid, block, 0, stream, g);
+            else hipLaunchKernelGGL((gemm_x6_kernel<false, false, 1, 2, 4, 1, EPI>), grid, block, 0, stream, g);
             VSOM_LAUNCH_CHECK("gemm_x6_kernel");
         }
     }
@@ -62,6 +62,12 @@ static int launch_t(GemmP& g, int splits, hipStream_t stream) {
             if (fast) hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, 1, 1, 2, 2, EPI, true>), grid, block, 0, stream, g);
             else hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, 1, 1, 2, 2, EPI, false>), grid, block, 0, stream, g);
             VSOM_LAUNCH_CHECK("gemm_f32_kernel");
+        }
+    }
+    if constexpr (A_KC && !B_KC && EPI == EPI_ROWAXPY) {
+        if (fast && gemm_mode() == VSOM_GEMM_SPLIT_BF16) {
+            hipLaunchKernelGGL((gemm_x6_kernel<true, false, 1, 2, 4, 1, EPI>), grid, block, 0, stream, g);
+            VSOM_LAUNCH_CHECK("gemm_x6_kernel");
         }
     }
     if constexpr (A_KC && B_KC && EPI != EPI_SLAB) {
@@ -74,10 +80,10 @@ static int launch_t(GemmP& g, int splits, hipStream_t stream) {
             const double c64 = rounds((long)cdiv(g.M, 64) * cdiv(g.N, 64) * splits) * 1.02;
             if (c64 < c128) {
                 dim3 grid64(cdiv(g.M, 64) * cdiv(g.N, 64) * splits, 1, 1);
-                hipLaunchKernelGGL((gemm_x6_kernel<true, 1, 1, 2, 2, EPI>), grid64, block, 0, stream, g);
+                hipLaunchKernelGGL((gemm_x6_kernel<true, true, 1, 1, 2, 2, EPI>), grid64, block, 0, stream, g);
                 VSOM_LAUNCH_CHECK("gemm_x6_kernel");
             }
-            hipLaunchKernelGGL((gemm_x6_kernel<true, 1, 2, 4, 1, EPI>), grid, block, 0, stream, g);
+            hipLaunchKernelGGL((gemm_x6_kernel<true, true, 1, 2, 4, 1, EPI>), grid, block, 0, stream, g);
             VSOM_LAUNCH_CHECK("gemm_x6_kernel");
         }
     }

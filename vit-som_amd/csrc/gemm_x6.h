@@ -12,10 +12,11 @@
 // error 1.3e-7 here vs 1.9e-7 for the v_mfma_f32_32x32x2_f32 engine.  The MFMA time per k drops
 // from 32 to 12 cycles per 32x32 tile; range and denormal behaviour are fp32's (no scaling).
 //
-// Layouts: KC = true, both operands k-contiguous ("NT": Y = X W^T; the input-gradient GEMM uses a
-// transposed weight copy so that it is NT too); KC = false, both k-strided ("TN": dW = dY^T X,
-// reduction over the token rows) -- there a thread loads a 4(k) x 4(cols) block, transposes it in
-// registers and writes the same k-contiguous bf16 planes, so the MFMA loop is shared.
+// Layouts, per operand: k-contiguous (both: "NT", Y = X W^T; the Linear input-gradient GEMM uses a
+// transposed weight copy so that it is NT too) or k-strided (both: "TN", dW = dY^T X, reduction
+// over the token rows; B only: "NN", the SOM input gradient coef W).  For a k-strided operand a
+// thread loads a 4(k) x 4(cols) block, transposes it in registers and writes the same
+// k-contiguous bf16 planes, so the MFMA loop is shared.
 // Tiles 128 x 64 x 32 (4 waves of 32 x 64) or 64 x 64 x 32 (2 x 2 waves of 32 x 32), register-staged like
 // gemm_f32.h; the split happens between the global load and the LDS store (4 and / 4 sub / 3
 // perm per pair of elements).  LDS holds three bf16 planes per operand, rows of 32 bf16 + 16 B
@@ -89,7 +90,7 @@ __device__ __forceinline__ void x6_store_ks(const X6Blk& b, char* planes, int pl
     }
 }
 
-template <bool KC, int WM, int WN, int WAVES_M, int WAVES_N, int EPI>
+template <bool A_KC, bool B_KC, int WM, int WN, int WAVES_M, int WAVES_N, int EPI>
 __global__ __launch_bounds__(256) void gemm_x6_kernel(const GemmP g) {
     constexpr int BM = WAVES_M * WM * 32;
     constexpr int BN = WAVES_N * WN * 32;
@@ -131,49 +132,41 @@ __global__ __launch_bounds__(256) void gemm_x6_kernel(const GemmP g) {
 
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.A), 0, (int)g.a_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.B), 0, (int)g.b_bytes, 0x00020000);
-    // k-contiguous staging state
-    StageRegs<KC ? BM : 32> sa;
-    StageRegs<KC ? BN : 32> sb;
-    OffKC<KC ? BM : 32> oa; OffKC<KC ? BN : 32> ob;
-    // k-strided staging state: A tasks on threads [0, 2 BM), B tasks on threads [256 - 2 BN, 256)
+    // per-operand staging state: k-contiguous operands use StageRegs / OffKC (all 256 threads),
+    // k-strided ones the 4x4 task map (A tasks on threads [0, 2 BM), B tasks on [256 - 2 BN, 256))
+    StageRegs<A_KC ? BM : 32> sa;
+    StageRegs<B_KC ? BN : 32> sb;
+    OffKC<A_KC ? BM : 32> oa; OffKC<B_KC ? BN : 32> ob;
     constexpr int TA = 2 * BM, TB0 = 256 - 2 * BN;
     static_assert(TA <= 256 && TB0 >= 0, "tile too large for the k-strided task map");
-    const bool has_a = !KC && t < TA, has_b = !KC && t >= TB0;
+    const bool has_a = !A_KC && t < TA, has_b = !B_KC && t >= TB0;
     const int kga = t & 7, mqa = t >> 3, kgb = (t - TB0) & 7, mqb = (t - TB0) >> 3;
     X6Blk ba, bb;
     unsigned cola = OOB, colb = OOB;
     float cs[4] = {0.f, 0.f, 0.f, 0.f};          // EPI_SLAB bias partial: column sums of A over this thread's k rows
-    const bool want_colsum = (EPI == EPI_SLAB) && !KC && g.slab_bias != nullptr && bn0 == 0;
-    if constexpr (KC) {
-        init_kc<BM>(oa, g.lda, bm0, g.M, t);
-        init_kc<BN>(ob, g.ldb, bn0, g.N, t);
-    } else {
-        if (has_a && bm0 + 4 * mqa < g.M) cola = (unsigned)(bm0 + 4 * mqa) << 2;
-        if (has_b && bn0 + 4 * mqb < g.N) colb = (unsigned)(bn0 + 4 * mqb) << 2;
-    }
+    const bool want_colsum = (EPI == EPI_SLAB) && !A_KC && g.slab_bias != nullptr && bn0 == 0;
+    if constexpr (A_KC) init_kc<BM>(oa, g.lda, bm0, g.M, t);
+    else if (has_a && bm0 + 4 * mqa < g.M) cola = (unsigned)(bm0 + 4 * mqa) << 2;
+    if constexpr (B_KC) init_kc<BN>(ob, g.ldb, bn0, g.N, t);
+    else if (has_b && bn0 + 4 * mqb < g.N) colb = (unsigned)(bn0 + 4 * mqb) << 2;
     auto gload = [&](int kt) {
-        if constexpr (KC) {
-            load_kc_fast<BM>(sa, rsA, oa, kt << 5, g.K, t);
-            load_kc_fast<BN>(sb, rsB, ob, kt << 5, g.K, t);
-        } else {
-            if (has_a) x6_load_ks(ba, rsA, cola, (unsigned)g.lda << 2, kt << 5, g.K, kga, g.a_seg, g.a_stride, g.a_off);
-            if (has_b) x6_load_ks(bb, rsB, colb, (unsigned)g.ldb << 2, kt << 5, g.K, kgb, 0, 0, 0);
-        }
+        if constexpr (A_KC) load_kc_fast<BM>(sa, rsA, oa, kt << 5, g.K, t);
+        else if (has_a) x6_load_ks(ba, rsA, cola, (unsigned)g.lda << 2, kt << 5, g.K, kga, g.a_seg, g.a_stride, g.a_off);
+        if constexpr (B_KC) load_kc_fast<BN>(sb, rsB, ob, kt << 5, g.K, t);
+        else if (has_b) x6_load_ks(bb, rsB, colb, (unsigned)g.ldb << 2, kt << 5, g.K, kgb, 0, 0, 0);
     };
     auto lstore = [&]() {
-        if constexpr (KC) {
+        if constexpr (A_KC) {
             x6_store<BM>(sa, As, t);
-            x6_store<BN>(sb, Bs, t);
-        } else {
-            if (has_a) {
-                if (want_colsum) {
+        } else if (has_a) {
+            if (want_colsum) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) cs[e] += (ba.v[0][e] + ba.v[1][e]) + (ba.v[2][e] + ba.v[3][e]);
-                }
-                x6_store_ks(ba, As, PA, mqa, kga);
+                for (int e = 0; e < 4; ++e) cs[e] += (ba.v[0][e] + ba.v[1][e]) + (ba.v[2][e] + ba.v[3][e]);
             }
-            if (has_b) x6_store_ks(bb, Bs, PB, mqb, kgb);
+            x6_store_ks(ba, As, PA, mqa, kga);
         }
+        if constexpr (B_KC) x6_store<BN>(sb, Bs, t);
+        else if (has_b) x6_store_ks(bb, Bs, PB, mqb, kgb);
     };
 
     if (kt_begin < kt_end) {
@@ -218,7 +211,7 @@ __global__ __launch_bounds__(256) void gemm_x6_kernel(const GemmP g) {
             __syncthreads();
         }
     }
-    if constexpr (EPI == EPI_SLAB && !KC) {
+    if constexpr (EPI == EPI_SLAB && !A_KC) {
         if (want_colsum && has_a) {              // the 8 k-groups of a column quad are 8 consecutive lanes
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
