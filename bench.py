@@ -21,6 +21,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense f32 MFMA peak (no xf32 on gfx950)
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA peak (no sparsity)
 
 
 def c3_config(batch):
@@ -62,6 +63,42 @@ def cpu_baseline(seconds_budget=25.0):
     dt = time.perf_counter() - t0
     return {"value": round(Bc * nsteps / dt, 2), "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"{nsteps} step(s) of the same c3 workload at batch {Bc} (fwd+bwd+AdamW, fp32 'highest') after 1 warm-up"}
+
+
+def secondary_kernels(ops, B, dev):
+    """SURVEY.md 8(d) also asks for the MFMA utilisation of the attention / Linear GEMMs: time the
+    encoder's qkv Linear and the attention forward on their own (outside the timed region), with
+    the peak each is quoted against."""
+    T, E, H, N = B * 65, 192, 3, 65
+    x = torch.randn(T, E, device=dev); W = torch.randn(3 * E, E, device=dev) * 0.05; b = torch.zeros(3 * E, device=dev)
+    qkv = torch.empty(T, 3 * E, device=dev); ao = torch.empty(T, E, device=dev); lse = torch.empty(B * H * N, device=dev)
+
+    def ms(fn, n=20):
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record(); torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / n
+
+    t_lin = ms(lambda: ops.linear_fwd(x, W, b, qkv))
+    t_att = ms(lambda: ops.attention_fwd(qkv, ao, lse, B, N, H, E // H))
+    split = ops.get_gemm_mode() == ops.GEMM_SPLIT_BF16
+    lin_tf = 2.0 * T * 3 * E * E / (t_lin * 1e-3) / 1e12
+    att_tf = 4.0 * B * H * N * N * (E // H) / (t_att * 1e-3) / 1e12
+    lin_peak = BF16_MFMA_PEAK_TFLOPS / 6.0 if split else F32_MFMA_PEAK_TFLOPS
+    return {
+        "linear_qkv_fwd": {"shape": [T, 3 * E, E], "ms": round(t_lin, 4), "achieved_f32_equiv_TFLOPs": round(lin_tf, 1),
+                           "peak_TFLOPs": round(lin_peak, 1), "frac": round(lin_tf / lin_peak, 3),
+                           "peak_basis": ("dense bf16 MFMA 2500 TF / 6 products per fp32 product" if split else "f32 MFMA"),
+                           "hbm_GBps": round(4.0 * (T * E + 3 * E * E + T * 3 * E) / (t_lin * 1e-3) / 1e9, 1)},
+        "attention_fwd": {"shape": {"images": B, "heads": H, "tokens": N, "head_dim": E // H}, "ms": round(t_att, 4),
+                          "achieved_TFLOPs": round(att_tf, 1), "peak_TFLOPs": F32_MFMA_PEAK_TFLOPS,
+                          "frac": round(att_tf / F32_MFMA_PEAK_TFLOPS, 3), "peak_basis": "f32 MFMA (16x16x4)",
+                          "hbm_GBps": round(4.0 * (T * 3 * E + T * E) / (t_att * 1e-3) / 1e9, 1)},
+    }
 
 
 def main():
@@ -165,6 +202,7 @@ def main():
                          "hbm_view": {"achieved_GBps": round(bmu_bytes / t_s / 1e9, 1), "peak_GBps": HBM_PEAK_GBS,
                                       "frac": round(bmu_bytes / t_s / 1e9 / HBM_PEAK_GBS, 4)}},
         }
+        out["secondary"] = secondary_kernels(ops, B, dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

@@ -36,6 +36,7 @@ typedef struct ihipStream_t* vsom_stream_t; /* == hipStream_t */
 
 #define VSOM_DIST_COSINE 0
 #define VSOM_DIST_EUCLIDEAN 1
+#define VSOM_DIST_MANHATTAN 2   /* torch.cdist(p=1) (models/som_layer.py:115-116; the DESOM configs' distance) */
 
 int vsom_version(void);
 const char* vsom_last_error_string(void);
@@ -176,6 +177,20 @@ int vsom_som_neigh_loss(const float* dist, const int64_t* bmu, const float* grid
 int vsom_som_bwd(const float* X, long ldx, const float* W, const float* coef, const float* row_dot,
                  const float* col_dot, float* gW, float* gX, long ldgx, int accumulate_gx, int B, int K,
                  int L, vsom_stream_t stream);
+
+/* manhattan BMU search: dist[B,K] = sum_l |X[i,l] - W[k,l]| (torch.cdist p=1, som_layer.py:115-116),
+ * bmu = first argmin.  Tiled VALU kernels (|x - w| has no dot-product form); the reduction over l is
+ * split into fp32 slabs in `ws`, summed in a fixed order.  dist may be NULL. */
+size_t vsom_bmu_manhattan_workspace_bytes(int B, int K, int L);
+int vsom_bmu_manhattan_fwd(const float* X, long ldx, const float* W, float* dist, int64_t* bmu, int B, int K,
+                           int L, void* ws, size_t ws_bytes, vsom_stream_t stream);
+
+/* Backward of som_loss through the manhattan distances, from coef = dLoss/d dist written by
+ * vsom_som_neigh_loss(distance = VSOM_DIST_MANHATTAN):
+ *   gW[k,l]   = -sum_i coef[i,k] sign(X[i,l] - W[k,l])
+ *   gX[i,l] (+)= sum_k coef[i,k] sign(X[i,l] - W[k,l])          (sign(0) = 0, as torch) */
+int vsom_som_bwd_manhattan(const float* X, long ldx, const float* W, const float* coef, float* gW, float* gX,
+                           long ldgx, int accumulate_gx, int B, int K, int L, vsom_stream_t stream);
 
 /* ------------------------------------------------------------------ losses */
 /* L1Loss(unpatchify(pred[:,1:,:]), img) -- vit.py:141-153,234-236 + vit_som.py:100.

@@ -103,6 +103,9 @@ CASES = {
     # the other SOMLayer variants: hexa topology + euclidean distance
     "ref_hexa_euclid_tiny": dict(cfg=make_config(1, 8, 2, 16, 1, 2, 8, 1, (4, 3), 0, 6, distance="euclidean",
                                                  topology="hexa"), B=6, it=5, n_train=60, est=40),
+    # manhattan distance (torch.cdist p=1, som_layer.py:115-116; the DESOM configs' distance)
+    "ref_manhattan_tiny": dict(cfg=make_config(1, 8, 2, 16, 1, 2, 8, 1, (3, 4), 0, 6, distance="manhattan"),
+                               B=5, it=4, n_train=60, est=40),
 }
 
 
@@ -190,8 +193,12 @@ def run_case(name, spec):
 def main():
     _install_stand_ins()
     os.makedirs(OUT, exist_ok=True)
+    only = sys.argv[1:]                      # optional case names: regenerate just those fixtures
     for name, spec in CASES.items():
-        run_case(name, spec)
+        if not only or name in only:
+            run_case(name, spec)
+    if only and "ref_lr_schedule" not in only:
+        return
     # scheduler known answers from the reference's own LambdaLR lambda (vit_som.py:160)
     from models.vit_som import ViTSOM
     cfg = copy.deepcopy(CASES["ref_cls_tiny"]["cfg"])

@@ -6,7 +6,7 @@ import numpy as np
 import torch
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-REF_CASES = ["ref_cluster_tiny", "ref_cls_tiny", "ref_mnistlike_tiny", "ref_hexa_euclid_tiny"]
+REF_CASES = ["ref_cluster_tiny", "ref_cls_tiny", "ref_mnistlike_tiny", "ref_hexa_euclid_tiny", "ref_manhattan_tiny"]
 
 
 def load_golden(name):

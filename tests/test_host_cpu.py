@@ -105,11 +105,11 @@ def test_compute_has_no_cpu_path():
         m(torch.from_numpy(z["x"]))
     with pytest.raises(ValueError):
         m.som_layer(torch.randn(2, m.som_layer.latent_dim))
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(ValueError):
         import vit_som_amd
         _, cfg = load_golden("ref_hexa_euclid_tiny")
-        cfg["hyperparameters"]["som"]["distance_fcn"] = "manhattan"
-        vit_som_amd.ViTSOM(cfg, device="cpu")       # manhattan distance (DESOM configs): no HIP kernel yet
+        cfg["hyperparameters"]["som"]["distance_fcn"] = "chebyshev"
+        vit_som_amd.ViTSOM(cfg, device="cpu")       # som_layer.py:124-125: unknown distance functions raise
 
 
 def test_patchify_roundtrip():

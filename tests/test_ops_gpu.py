@@ -456,3 +456,39 @@ def test_som_euclidean_fwd_and_bwd(ops, O, gemm_mode, B, K, L, map_size, topo):
     gW, gX = torch.empty(K, L, device=DEV), torch.zeros(B, L, device=DEV)
     ops.som_bwd(xd, Wd, coef, rd, cd, gW, gX, accumulate_gx=False)
     assert rel_err(gW.cpu(), Wl.grad) < 5e-5 and rel_err(gX.cpu(), xl.grad) < 5e-5
+
+
+@pytest.mark.parametrize("B,K,L,map_size,topo", [(64, 100, 3136, (10, 10), "square"), (33, 12, 48, (4, 3), "hexa"),
+                                                  (5, 7, 21, (7, 1), "square"), (130, 70, 200, (10, 7), "square")])
+def test_som_manhattan_fwd_and_bwd(ops, O, B, K, L, map_size, topo):
+    """manhattan distance variant (torch.cdist p=1, som_layer.py:115-116) + its SOM-loss gradients
+    (SURVEY 8(f) N4); ragged shapes exercise the scalar tails (L = 21 is not a multiple of 4)."""
+    x = rnd(B, L, seed=1)
+    W = torch.rand(K, L, generator=torch.Generator().manual_seed(2))
+    x[0, :3] = W[1, :3]                                   # exact zeros of x - w: sign(0) = 0 like torch
+    grid = O.grid_positions(map_size, topo)
+    T, gam = 2.3, 0.5
+    xl, Wl = x.clone().double().requires_grad_(True), W.clone().double().requires_grad_(True)
+    d_ref = torch.cdist(xl, Wl, p=1)
+    bmu_ref = d_ref.argmin(1)
+    loss_ref = O.som_loss(O.neighbourhood(bmu_ref, grid.double(), T), d_ref)
+    (gam * loss_ref).backward()
+    xd, Wd = dev(x), dev(W)
+    dist, bmu = torch.empty(B, K, device=DEV), torch.empty(B, dtype=torch.int64, device=DEV)
+    ops.bmu_manhattan_fwd(xd, Wd, dist, bmu)
+    assert rel_err(dist.cpu(), d_ref.detach()) < 2e-6
+    assert torch.equal(bmu.cpu(), dist.cpu().argmin(1)) and torch.equal(bmu.cpu(), bmu_ref)
+    bmu2 = torch.empty(B, dtype=torch.int64, device=DEV)
+    ops.bmu_manhattan_fwd(xd, Wd, None, bmu2)             # index-only form
+    assert torch.equal(bmu2, bmu)
+    loss = torch.zeros(1, device=DEV)
+    coef = torch.empty(B, K, device=DEV)
+    ops.som_neigh_loss(dist, bmu, dev(grid), T, loss, grad_scale=gam / (B * K), coef=coef, distance=ops.DIST_MANHATTAN)
+    assert abs(float(loss) / (B * K) - float(loss_ref.detach())) < 1e-5 * float(loss_ref.detach())
+    gW, gX = torch.empty(K, L, device=DEV), torch.zeros(B, L, device=DEV)
+    ops.som_bwd_manhattan(xd, Wd, coef, gW, gX, accumulate_gx=False)
+    assert rel_err(gW.cpu(), Wl.grad) < 5e-6 and rel_err(gX.cpu(), xl.grad) < 5e-6
+    base = rnd(B, L, seed=9)
+    gX2 = dev(base).clone()
+    ops.som_bwd_manhattan(xd, Wd, coef, gW, gX2, accumulate_gx=True)
+    assert rel_err(gX2.cpu(), xl.grad + base.double()) < 5e-6

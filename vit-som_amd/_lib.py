@@ -46,6 +46,11 @@ SIGNATURES = {
     "vsom_row_sqnorm": (C.c_int, [c_fp, C.c_long, C.c_int, C.c_int, c_fp, c_stream]),
     "vsom_bmu_euclid_fwd": (C.c_int, [c_fp, C.c_long, c_fp, c_fp, c_fp, c_fp, c_fp, C.c_int, C.c_int, C.c_int, c_fp,
                                       C.c_size_t, c_stream]),
+    "vsom_bmu_manhattan_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "vsom_bmu_manhattan_fwd": (C.c_int, [c_fp, C.c_long, c_fp, c_fp, c_fp, C.c_int, C.c_int, C.c_int, c_fp, C.c_size_t,
+                                         c_stream]),
+    "vsom_som_bwd_manhattan": (C.c_int, [c_fp, C.c_long, c_fp, c_fp, c_fp, c_fp, C.c_long, C.c_int, C.c_int, C.c_int,
+                                         C.c_int, c_stream]),
     "vsom_bmu_cosine_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "vsom_bmu_cosine_fwd": (C.c_int, [c_fp, C.c_long, c_fp, c_fp, c_fp, c_fp, c_fp, C.c_int, C.c_int, C.c_int, c_fp,
                                       C.c_size_t, c_stream]),

@@ -6,12 +6,12 @@ OUT="${1:-$HERE/..}"
 mkdir -p "$HERE/obj"
 FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wall -Wno-unused-function"
 pids=()
-for f in gemm_f32 som layernorm attention misc; do
-  if [ ! -f "$HERE/obj/$f.o" ] || [ "$HERE/$f.hip" -nt "$HERE/obj/$f.o" ] || [ "$HERE/gemm_f32.h" -nt "$HERE/obj/$f.o" ] || [ "$HERE/common.h" -nt "$HERE/obj/$f.o" ] || [ "$HERE/../../include/vitsom_hip.h" -nt "$HERE/obj/$f.o" ]; then
+for f in gemm_f32 som som_l1 layernorm attention misc; do
+  if [ ! -f "$HERE/obj/$f.o" ] || [ "$HERE/$f.hip" -nt "$HERE/obj/$f.o" ] || [ "$HERE/gemm_f32.h" -nt "$HERE/obj/$f.o" ] || [ "$HERE/gemm_x6.h" -nt "$HERE/obj/$f.o" ] || [ "$HERE/common.h" -nt "$HERE/obj/$f.o" ] || [ "$HERE/../../include/vitsom_hip.h" -nt "$HERE/obj/$f.o" ]; then
     hipcc $FLAGS -c "$HERE/$f.hip" -o "$HERE/obj/$f.o" &
     pids+=($!)
   fi
 done
 for p in "${pids[@]}"; do wait $p; done
-hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT/libvitsom_hip.so" "$HERE"/obj/{gemm_f32,som,layernorm,attention,misc}.o
+hipcc --offload-arch=gfx950 -shared -fPIC -o "$OUT/libvitsom_hip.so" "$HERE"/obj/{gemm_f32,som,som_l1,layernorm,attention,misc}.o
 echo "built $OUT/libvitsom_hip.so"

@@ -38,14 +38,15 @@ __global__ __launch_bounds__(256) void bmu_finalize_kernel(const float* __restri
                                                            float* __restrict__ dist, int64_t* __restrict__ bmu,
                                                            int K, int euclid) {
     const int i = blockIdx.x;
-    const float rx = inv_nx[i];          // cosine: 1/|x_i| ; euclidean: |x_i|^2
+    const float rx = inv_nx ? inv_nx[i] : 0.f;   // cosine: 1/|x_i| ; euclidean: |x_i|^2 ; manhattan (euclid == 2): unused
     float best = INFINITY;
     int bidx = 0x7fffffff;
     for (int k = threadIdx.x; k < K; k += 256) {
         float dot = 0.f;
         for (int s = 0; s < nslabs; ++s) dot += slab[(long)s * slab_stride + (long)i * K + k];
         // euclidean: torch.cdist's matmul form  sqrt(clamp_min(|x|^2 + |w|^2 - 2 x.w, 1e-30))
-        const float d = euclid ? sqrtf(fmaxf(fmaf(-2.0f, dot, rx + inv_nw[k]), 1e-30f)) : 1.0f - dot * rx * inv_nw[k];
+        const float d = euclid == 2 ? dot        // manhattan: the slabs already hold partial distances
+                      : euclid ? sqrtf(fmaxf(fmaf(-2.0f, dot, rx + inv_nw[k]), 1e-30f)) : 1.0f - dot * rx * inv_nw[k];
         if (dist) dist[(long)i * K + k] = d;
         if (d < best || (d == best && k < bidx)) { best = d; bidx = k; }
     }
@@ -91,7 +92,9 @@ __global__ __launch_bounds__(256) void som_neigh_row_kernel(const float* __restr
         const float h = expf(-(dy * dy + dx * dx) * inv_2T2);
         const float d = dist[(long)i * K + k];
         if (h_out) h_out[(long)i * K + k] = h;
-        if (euclid) {
+        if (euclid == 2) {                                      // manhattan: dLoss/d dist = c h
+            if (coef) coef[(long)i * K + k] = c * h;
+        } else if (euclid) {
             const float hd = (d > 0.f) ? h / d : 0.f;           // d|x-w|/dx = (x-w)/d ; torch gives 0 at d == 0
             if (coef) coef[(long)i * K + k] = -c * hd;
             dsum += hd;
@@ -156,6 +159,13 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restri
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
     __syncthreads();
     if (threadIdx.x == 0) out[0] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+int bmu_finalize_plain(const float* slab, long slab_stride, int nslabs, float* dist, int64_t* bmu, int B, int K,
+                       hipStream_t stream) {
+    hipLaunchKernelGGL(bmu_finalize_kernel, dim3(B), dim3(256), 0, stream, slab, slab_stride, nslabs, (const float*)nullptr,
+                       (const float*)nullptr, dist, bmu, K, 2);
+    VSOM_LAUNCH_CHECK("bmu_finalize_kernel");
 }
 
 int sum_partials(const float* part, int n, float* out, hipStream_t stream) {
@@ -240,14 +250,14 @@ int vsom_som_neigh_loss(const float* dist, const int64_t* bmu, const float* grid
                         const float* inv_nw, float grad_scale, float* h, float* loss_sum, float* coef,
                         float* row_dot, float* col_dot, int B, int K, int distance, void* ws, size_t ws_bytes,
                         vsom_stream_t stream) {
-    VSOM_REQUIRE(distance == VSOM_DIST_COSINE || distance == VSOM_DIST_EUCLIDEAN, VSOM_EUNSUPPORTED,
-                 "som_neigh_loss: distance %d not supported", distance);
-    const int euclid = distance == VSOM_DIST_EUCLIDEAN;
+    VSOM_REQUIRE(distance == VSOM_DIST_COSINE || distance == VSOM_DIST_EUCLIDEAN || distance == VSOM_DIST_MANHATTAN,
+                 VSOM_EUNSUPPORTED, "som_neigh_loss: distance %d not supported", distance);
+    const int euclid = distance == VSOM_DIST_EUCLIDEAN ? 1 : (distance == VSOM_DIST_MANHATTAN ? 2 : 0);
     VSOM_REQUIRE(dist && bmu && grid && loss_sum, VSOM_EINVAL, "som_neigh_loss: null pointer");
     VSOM_REQUIRE(B > 0 && K > 0 && T > 0.f, VSOM_EINVAL, "som_neigh_loss: bad shape/temperature");
     VSOM_REQUIRE(ws && ws_bytes >= vsom_som_neigh_workspace_bytes(B, K), VSOM_EWORKSPACE, "som_neigh_loss: workspace too small");
     const bool bwd = coef || row_dot || col_dot;
-    VSOM_REQUIRE(!bwd || (coef && row_dot && col_dot && (euclid || (inv_nx && inv_nw))), VSOM_EINVAL,
+    VSOM_REQUIRE(!bwd || (euclid == 2 && coef) || (coef && row_dot && col_dot && (euclid || (inv_nx && inv_nw))), VSOM_EINVAL,
                  "som_neigh_loss: backward outputs need coef, row_dot, col_dot (and inv_nx, inv_nw for cosine) together");
     const float inv_2T2 = (float)(1.0 / (2.0 * (double)T * (double)T));
     float* part = static_cast<float*>(ws);
@@ -257,7 +267,7 @@ int vsom_som_neigh_loss(const float* dist, const int64_t* bmu, const float* grid
     if (rc) return rc;
     rc = sum_partials(part, B, loss_sum, stream);
     if (rc) return rc;
-    if (bwd) {
+    if (bwd && euclid != 2) {
         hipLaunchKernelGGL(som_neigh_col_kernel, dim3(cdiv(K, 32)), dim3(256), 0, stream, dist, bmu, grid, inv_2T2,
                            inv_nw, grad_scale, col_dot, B, K, euclid);
         rc = hip_status(hipGetLastError(), "som_neigh_col_kernel");

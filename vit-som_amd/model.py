@@ -388,11 +388,10 @@ class SOMLayer(_Base):
         self.n_prototypes = int(np.prod(self.map_size))
         if self.model_arch != "vit_som":
             raise NotImplementedError("only model_arch == 'vit_som' is on the accelerated path")
-        if self.distance_fcn not in ("cosine", "euclidean"):
-            raise NotImplementedError(
-                f"distance_fcn={self.distance_fcn!r}: 'cosine' (every shipped vit_som config) and 'euclidean' have HIP "
-                "kernels; 'manhattan' (DESOM configs) does not yet")
-        self._dist_mode = ops.DIST_COSINE if self.distance_fcn == "cosine" else ops.DIST_EUCLIDEAN
+        modes = {"cosine": ops.DIST_COSINE, "euclidean": ops.DIST_EUCLIDEAN, "manhattan": ops.DIST_MANHATTAN}
+        if self.distance_fcn not in modes:                              # som_layer.py:111-125 raises the same way
+            raise ValueError(f"Unsupported distance function: {self.distance_fcn}")
+        self._dist_mode = modes[self.distance_fcn]
         self.use_reduced = som_hp["use_reduced"]
         latent_dim = vit_hp["emb_dim"]
         if not self.use_reduced:
@@ -452,6 +451,8 @@ class SOMLayer(_Base):
             ops.row_inv_norm(x2d, s.inx)
             ops.row_inv_norm(self.prototypes, s.inw)
             ops.bmu_cosine_fwd(x2d, self.prototypes, s.inx, s.inw, s.dist, s.bmu)
+        elif self._dist_mode == ops.DIST_MANHATTAN:
+            ops.bmu_manhattan_fwd(x2d, self.prototypes, s.dist, s.bmu)
         else:                                   # euclidean: inx / inw hold the squared norms
             ops.row_sqnorm(x2d, s.inx)
             ops.row_sqnorm(self.prototypes, s.inw)
@@ -877,8 +878,12 @@ class ViTSOM(_Base):
             gX = torch.as_strided(a.d_xe, (a.B, E), (N * E, 1), a.d_xe.storage_offset())
         else:
             gX = torch.as_strided(a.d_xe, (a.B, (N - 1) * E), (N * E, 1), a.d_xe.storage_offset() + E)
-        ops.som_bwd(X, self.som_layer.prototypes, s.coef, s.row_dot, s.col_dot, self._grad_views["som_layer.prototypes"],
-                    gX, accumulate_gx=True)
+        if self.som_layer._dist_mode == ops.DIST_MANHATTAN:
+            ops.som_bwd_manhattan(X, self.som_layer.prototypes, s.coef, self._grad_views["som_layer.prototypes"], gX,
+                                  accumulate_gx=True)
+        else:
+            ops.som_bwd(X, self.som_layer.prototypes, s.coef, s.row_dot, s.col_dot,
+                        self._grad_views["som_layer.prototypes"], gX, accumulate_gx=True)
         self._start_prototype_allreduce()
         self.vit._encoder_bwd(a, Gv, self._WT)
 

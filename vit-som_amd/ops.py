@@ -216,7 +216,7 @@ def row_inv_norm(x, out, eps=1e-12):
     return out
 
 
-DIST_COSINE, DIST_EUCLIDEAN = 0, 1
+DIST_COSINE, DIST_EUCLIDEAN, DIST_MANHATTAN = 0, 1, 2
 
 
 def row_sqnorm(x, out):
@@ -236,6 +236,25 @@ def bmu_euclid_fwd(x, W, sq_x, sq_w, dist: Optional[torch.Tensor], bmu):
     check(lib.vsom_bmu_euclid_fwd(ptr(x), _rows(x), ptr(W), ptr(sq_x), ptr(sq_w), ptr(dist), ptr(bmu), B, K, L, ptr(ws),
                                   ws.numel(), stream()), "vsom_bmu_euclid_fwd")
     return dist, bmu
+
+
+def bmu_manhattan_fwd(x, W, dist: Optional[torch.Tensor], bmu):
+    B, L = x.shape
+    K = W.shape[0]
+    _f32(x, "x"); _f32(W, "W")
+    assert W.is_contiguous() and W.shape[1] == L and bmu.dtype == torch.int64 and (dist is None or dist.is_contiguous())
+    ws = scratch(lib.vsom_bmu_manhattan_workspace_bytes(B, K, L), x.device)
+    check(lib.vsom_bmu_manhattan_fwd(ptr(x), _rows(x), ptr(W), ptr(dist), ptr(bmu), B, K, L, ptr(ws), ws.numel(), stream()),
+          "vsom_bmu_manhattan_fwd")
+    return dist, bmu
+
+
+def som_bwd_manhattan(x, W, coef, gW, gX, accumulate_gx=True):
+    B, L = x.shape
+    K = W.shape[0]
+    assert W.is_contiguous() and coef.is_contiguous() and gW.is_contiguous()
+    check(lib.vsom_som_bwd_manhattan(ptr(x), _rows(x), ptr(W), ptr(coef), ptr(gW), ptr(gX), _rows(gX), int(accumulate_gx),
+                                     B, K, L, stream()), "vsom_som_bwd_manhattan")
 
 
 def bmu_cosine_fwd(x, W, inv_nx, inv_nw, dist: Optional[torch.Tensor], bmu):
