@@ -53,6 +53,12 @@ int vsom_linear_fwd(const float* X, long ldx, const float* W, const float* bias,
 int vsom_linear_gelu_fwd(const float* X, long ldx, const float* W, const float* bias, float* Ygrad,
                          float* Yact, int M, int N, int K, vsom_stream_t stream);
 
+/* pre = X*W^T + bias ; Yact = max(pre, 0) ; Ygrad = (pre > 0) as 1.0 / 0.0   -- nn.Linear + nn.ReLU of the
+ * DESOM autoencoder (models/ae.py:44-59).  Same contract as vsom_linear_gelu_fwd: the backward is
+ * vsom_linear_bwd_input*(…, gelu_grad = Ygrad). */
+int vsom_linear_relu_fwd(const float* X, long ldx, const float* W, const float* bias, float* Ygrad,
+                         float* Yact, int M, int N, int K, vsom_stream_t stream);
+
 /* Y[m] = X[m]*W^T + bias + R[m % r_mod]   -- Linear + residual add (attn.proj vit.py:38,61;
  * mlp.2 vit.py:55,62: r_mod = M, R = block input) and Linear + broadcast table
  * (decoder_embed + decoder_pos_embed vit.py:225-226: r_mod = tokens per image). */
@@ -193,6 +199,12 @@ int vsom_som_bwd_manhattan(const float* X, long ldx, const float* W, const float
                            long ldgx, int accumulate_gx, int B, int K, int L, vsom_stream_t stream);
 
 /* ------------------------------------------------------------------ losses */
+/* loss_sum[0] = sum_i |pred[i] - target[i]| over n elements (nn.L1Loss numerator, models/desom.py:44,146);
+ * dpred[i] = grad_scale * sign(pred[i] - target[i]) when dpred != NULL.  Fixed-order reduction through `ws`. */
+size_t vsom_l1_loss_workspace_bytes(long n);
+int vsom_l1_loss(const float* pred, const float* target, float* loss_sum, float* dpred, float grad_scale, long n,
+                 void* ws, size_t ws_bytes, vsom_stream_t stream);
+
 /* L1Loss(unpatchify(pred[:,1:,:]), img) -- vit.py:141-153,234-236 + vit_som.py:100.
  * pred [B, n+1, p*p*C] (row 0 of each image = CLS prediction, ignored); img [B,C,S,S].
  * recon [B,C,S,S] (may be NULL); loss_sum[0] = sum |recon-img| (caller divides by B*C*S*S);

@@ -492,3 +492,30 @@ def test_som_manhattan_fwd_and_bwd(ops, O, B, K, L, map_size, topo):
     gX2 = dev(base).clone()
     ops.som_bwd_manhattan(xd, Wd, coef, gW, gX2, accumulate_gx=True)
     assert rel_err(gX2.cpu(), xl.grad + base.double()) < 5e-6
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 500, 784), (37, 64, 16), (70, 10, 2000), (256, 2000, 500)])
+def test_linear_relu_fwd(ops, gemm_mode, M, N, K):
+    """nn.Linear + nn.ReLU of the DESOM autoencoder (ae.py:44-59): activation and its 0/1 derivative."""
+    x, W, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.1), rnd(N, seed=3)
+    pre = x.double() @ W.double().T + b.double()
+    der, act = torch.empty(M, N, device=DEV), torch.empty(M, N, device=DEV)
+    ops.linear_relu_fwd(dev(x), dev(W), dev(b), der, act)
+    assert rel_err(act.cpu(), pre.clamp_min(0)) < GEMM_TOL
+    sure = pre.abs() > 1e-4                                  # away from the kink the mask is exact
+    assert torch.equal(der.cpu()[sure], (pre > 0).float()[sure])
+    assert set(der.cpu().unique().tolist()) <= {0.0, 1.0}
+
+
+@pytest.mark.parametrize("n", [7, 1024, 128 * 784 + 3])
+def test_l1_loss(ops, n):
+    p, t = rnd(n, seed=1), rnd(n, seed=2)
+    p[:2] = t[:2]                                            # sign(0) = 0
+    loss = torch.zeros(1, device=DEV)
+    dp = torch.empty(n, device=DEV)
+    ops.l1_loss(dev(p), dev(t), loss, dpred=dp, grad_scale=0.25)
+    assert abs(float(loss) - float((p.double() - t.double()).abs().sum())) < 1e-5 * n ** 0.5 + 1e-6
+    assert torch.equal(dp.cpu(), 0.25 * torch.sign(p - t))
+    loss2 = torch.zeros(1, device=DEV)
+    ops.l1_loss(dev(p), dev(t), loss2)
+    assert float(loss2) == float(loss)

@@ -3,4 +3,5 @@
 from . import _lib  # noqa: F401  (fails loudly when libvitsom_hip.so is absent)
 from . import ops  # noqa: F401
 from .model import FusedAdamW, SOMLayer, ViTAutoencoder, ViTSOM, param_groups_lrd  # noqa: F401,E402
+from .desom import DESOM, Autoencoder  # noqa: F401,E402
 from . import evaluation  # noqa: F401,E402

@@ -20,6 +20,9 @@ SIGNATURES = {
     "vsom_last_error_string": (C.c_char_p, []),
     "vsom_linear_fwd": (C.c_int, [c_fp, C.c_long, c_fp, c_fp, c_fp, C.c_long, C.c_int, C.c_int, C.c_int, c_stream]),
     "vsom_linear_gelu_fwd": (C.c_int, [c_fp, C.c_long, c_fp, c_fp, c_fp, c_fp, C.c_int, C.c_int, C.c_int, c_stream]),
+    "vsom_linear_relu_fwd": (C.c_int, [c_fp, C.c_long, c_fp, c_fp, c_fp, c_fp, C.c_int, C.c_int, C.c_int, c_stream]),
+    "vsom_l1_loss_workspace_bytes": (C.c_size_t, [C.c_long]),
+    "vsom_l1_loss": (C.c_int, [c_fp, c_fp, c_fp, c_fp, C.c_float, C.c_long, c_fp, C.c_size_t, c_stream]),
     "vsom_linear_residual_fwd": (C.c_int, [c_fp, C.c_long, c_fp, c_fp, c_fp, C.c_long, C.c_int, c_fp, C.c_long,
                                            C.c_int, C.c_int, C.c_int, c_stream]),
     "vsom_linear_bwd_input": (C.c_int, [c_fp, C.c_long, c_fp, c_fp, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int,

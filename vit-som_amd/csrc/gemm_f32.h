@@ -32,6 +32,7 @@ enum Epi : int {
     EPI_ROWAXPY = 4,    // v = acc + rowscale[m]*R[m*ldr + n] (+ C if accumulate)
     EPI_GELU_BWD = 5,   // v = acc * R[m*ldr + n] (R = gelu'(pre) saved by the forward) (+ C if accumulate)
     EPI_SLAB = 6,       // split-k partial: slab[z][m*N + n] = acc; optional column sums of A
+    EPI_BIAS_RELU = 7,  // pre = acc + bias[n]; C = (pre > 0) as 1.0/0.0 (the derivative); C2 = max(pre, 0)
 };
 
 struct GemmP {
@@ -190,7 +191,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& g, const f32x16 (&acc
             if (n >= g.N) continue;
             const int mb = m0 + i * 32 + 4 * h;
             float bn = 0.f;
-            if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RES) bn = g.bias ? g.bias[n] : 0.f;
+            if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RELU || EPI == EPI_BIAS_RES) bn = g.bias ? g.bias[n] : 0.f;
             if constexpr (EPI == EPI_SLAB) {
                 float* dst = g.slab + (long)z * g.slab_stride + (long)mb * g.N + n;
 #pragma unroll
@@ -212,7 +213,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& g, const f32x16 (&acc
                 const float* rsrc = nullptr;
                 float* dst2 = nullptr;
                 if constexpr (EPI == EPI_ROWAXPY || EPI == EPI_GELU_BWD) rsrc = g.R + (long)mb * g.ldr + n;
-                if constexpr (EPI == EPI_BIAS_GELU) dst2 = g.C2 + (long)mb * g.ldc2 + n;
+                if constexpr (EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RELU) dst2 = g.C2 + (long)mb * g.ldc2 + n;
                 const bool plain_res = (EPI == EPI_BIAS_RES) && g.r_mod >= g.M && g.r_off == 0;
                 if constexpr (EPI == EPI_BIAS_RES) rsrc = g.R + (long)mb * g.ldr + n;
 #pragma unroll
@@ -233,6 +234,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& g, const f32x16 (&acc
                         gelu_erf_both(a + bn, act, grad);
                         *d = grad;
                         dst2[(long)dm * g.ldc2] = act;
+                    } else if constexpr (EPI == EPI_BIAS_RELU) {
+                        const float pre = a + bn;
+                        *d = pre > 0.f ? 1.0f : 0.f;
+                        dst2[(long)dm * g.ldc2] = fmaxf(pre, 0.f);
                     } else if constexpr (EPI == EPI_BIAS_RES) {
                         const float rv = plain_res ? rsrc[(long)dm * g.ldr] : g.R[((long)(m % g.r_mod) + g.r_off) * g.ldr + n];
                         *d = a + bn + rv;

@@ -110,6 +110,7 @@ int launch_gemm(bool a_kc, bool b_kc, int epi, GemmP g, int splits, hipStream_t 
         switch (epi) {
             case EPI_BIAS: return launch_t<true, true, EPI_BIAS>(g, splits, stream);
             case EPI_BIAS_GELU: return launch_t<true, true, EPI_BIAS_GELU>(g, splits, stream);
+            case EPI_BIAS_RELU: return launch_t<true, true, EPI_BIAS_RELU>(g, splits, stream);
             case EPI_BIAS_RES: return launch_t<true, true, EPI_BIAS_RES>(g, splits, stream);
             case EPI_SLAB: return launch_t<true, true, EPI_SLAB>(g, splits, stream);
             case EPI_NONE: return launch_t<true, true, EPI_NONE>(g, splits, stream);
@@ -312,6 +313,16 @@ int vsom_linear_gelu_fwd(const float* X, long ldx, const float* W, const float* 
     g.A = X; g.lda = ldx; g.B = W; g.ldb = K; g.C = Ypre; g.ldc = N; g.C2 = Yact; g.ldc2 = N;
     g.M = M; g.N = N; g.K = K; g.bias = bias;
     return launch_gemm(true, true, EPI_BIAS_GELU, g, 1, stream);
+}
+
+int vsom_linear_relu_fwd(const float* X, long ldx, const float* W, const float* bias, float* Ygrad, float* Yact,
+                         int M, int N, int K, vsom_stream_t stream) {
+    VSOM_REQUIRE(X && W && Ygrad && Yact, VSOM_EINVAL, "linear_relu_fwd: null pointer");
+    VSOM_REQUIRE(ldx >= K, VSOM_EINVAL, "linear_relu_fwd: leading dimension too small");
+    GemmP g = {};
+    g.A = X; g.lda = ldx; g.B = W; g.ldb = K; g.C = Ygrad; g.ldc = N; g.C2 = Yact; g.ldc2 = N;
+    g.M = M; g.N = N; g.K = K; g.bias = bias;
+    return launch_gemm(true, true, EPI_BIAS_RELU, g, 1, stream);
 }
 
 int vsom_linear_residual_fwd(const float* X, long ldx, const float* W, const float* bias, const float* R,

@@ -95,6 +95,23 @@ __global__ __launch_bounds__(256) void l1_unpatchify_kernel(const float* __restr
     if (threadIdx.x == 0) part[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
 
+// plain L1 over n elements (+ sign gradient)
+__global__ __launch_bounds__(256) void l1_loss_kernel(const float* __restrict__ pred, const float* __restrict__ target,
+                                                      float* __restrict__ part, float* __restrict__ dpred, float gscale,
+                                                      long n) {
+    float acc = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float d = pred[i] - target[i];
+        acc += fabsf(d);
+        if (dpred) dpred[i] = (d > 0.f) ? gscale : ((d < 0.f) ? -gscale : 0.f);
+    }
+    acc = wave_sum(acc);
+    __shared__ float sh[4];
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
 static int l1_blocks(long total) {
     long b = (total + 1023) / 1024;
     if (b > 2048) b = 2048;
@@ -268,6 +285,20 @@ size_t vsom_l1_unpatchify_workspace_bytes(int B, int C, int S, int p) {
     if (B <= 0 || C <= 0 || S <= 0 || p <= 0) return 0;
     const int g = S / p;
     return (size_t)l1_blocks((long)B * (g * g + 1) * p * p * C) * sizeof(float);
+}
+
+size_t vsom_l1_loss_workspace_bytes(long n) { return n > 0 ? (size_t)l1_blocks(n) * sizeof(float) : 0; }
+
+int vsom_l1_loss(const float* pred, const float* target, float* loss_sum, float* dpred, float grad_scale, long n,
+                 void* ws, size_t ws_bytes, vsom_stream_t stream) {
+    VSOM_REQUIRE(pred && target && loss_sum && n > 0, VSOM_EINVAL, "l1_loss: bad arguments");
+    VSOM_REQUIRE(ws && ws_bytes >= vsom_l1_loss_workspace_bytes(n), VSOM_EWORKSPACE, "l1_loss: workspace too small");
+    const int nblk = l1_blocks(n);
+    float* part = static_cast<float*>(ws);
+    hipLaunchKernelGGL(l1_loss_kernel, dim3(nblk), dim3(256), 0, stream, pred, target, part, dpred, grad_scale, n);
+    int rc = hip_status(hipGetLastError(), "l1_loss_kernel");
+    if (rc) return rc;
+    return sum_partials(part, nblk, loss_sum, stream);
 }
 
 int vsom_l1_unpatchify(const float* pred, const float* img, float* recon, float* loss_sum, float* dpred,

@@ -373,7 +373,8 @@ class ViTAutoencoder(nn.Module):
 
 # ------------------------------------------------------------------------------------ SOM layer
 class SOMLayer(_Base):
-    """models/som_layer.py:8-152 on the HIP kernels (cosine distance; square / hexa topology)."""
+    """models/som_layer.py:8-152 on the HIP kernels (cosine / euclidean / manhattan distance; square /
+    hexa topology; clients: ViTSOM and DESOM)."""
 
     def __init__(self, config):
         super().__init__()
@@ -386,16 +387,18 @@ class SOMLayer(_Base):
         self.Tmax, self.Tmin = som_hp["Tmax"], som_hp["Tmin"]
         self.topology, self.distance_fcn = som_hp["topology"], som_hp["distance_fcn"]
         self.n_prototypes = int(np.prod(self.map_size))
-        if self.model_arch != "vit_som":
-            raise NotImplementedError("only model_arch == 'vit_som' is on the accelerated path")
         modes = {"cosine": ops.DIST_COSINE, "euclidean": ops.DIST_EUCLIDEAN, "manhattan": ops.DIST_MANHATTAN}
         if self.distance_fcn not in modes:                              # som_layer.py:111-125 raises the same way
             raise ValueError(f"Unsupported distance function: {self.distance_fcn}")
         self._dist_mode = modes[self.distance_fcn]
-        self.use_reduced = som_hp["use_reduced"]
-        latent_dim = vit_hp["emb_dim"]
-        if not self.use_reduced:
-            latent_dim *= (data_hp["input_size"] // vit_hp["patch_size"]) ** 2
+        if self.model_arch == "vit_som":                                       # som_layer.py:35-40
+            self.use_reduced = som_hp["use_reduced"]
+            latent_dim = vit_hp["emb_dim"]
+            if not self.use_reduced:
+                latent_dim *= (data_hp["input_size"] // vit_hp["patch_size"]) ** 2
+        else:                                                                  # DESOM: the autoencoder's code
+            self.use_reduced = False
+            latent_dim = hp["ae"]["encoder_dims"][-1]
         self.latent_dim = latent_dim
         self.current_temperature = self.Tmax
         proto = torch.rand(self.n_prototypes, latent_dim)                      # som_layer.py:44-56
@@ -619,8 +622,121 @@ class _StepLoss(torch.autograd.Function):
         return None, None, None, None, None, None
 
 
+# ------------------------------------------------------------------------------------ arena owner
+class _ArenaOwner:
+    """What every model on this path shares: trainable tensors packed into flat arenas
+    (arena.py), gradients exposed as views, and the data-parallel exchange over the gradient
+    arena.  Subclasses provide ``som_layer`` and may override the two hooks."""
+
+    arena: Optional[ParamArena] = None
+    world_size, rank = 1, 0
+    _grads_reduced = False
+    _early = None
+
+    def _default_weight_decay(self, name: str, p) -> float:
+        return 0.0
+
+    def _after_pack(self):
+        pass
+
+    def _named_trainable(self):
+        return [(n, p) for n, p in self.named_parameters() if p.requires_grad]
+
+    def _pack(self, device):
+        """(Re)build the flat arenas on `device` and re-point every Parameter at its view."""
+        old_wd = self.arena.wd_by_name if self.arena is not None else {}
+        named = self._named_trainable()
+        specs = []
+        for n, p in named:
+            wd = old_wd[n] if n in old_wd else self._default_weight_decay(n, p)
+            specs.append((n, tuple(p.shape), wd))
+        arena = ParamArena(specs, device)
+        with torch.no_grad():
+            for n, p in named:
+                v = arena.p(n)
+                v.copy_(p.detach().to(device))
+                p.data = v
+            for n, b in list(self.named_buffers()) + [(n, p) for n, p in self.named_parameters() if not p.requires_grad]:
+                if b.device != device:
+                    b.data = b.data.to(device)
+        if self.arena is not None and self.arena.device == device:
+            arena.exp_avg.copy_(self.arena.exp_avg)
+            arena.exp_avg_sq.copy_(self.arena.exp_avg_sq)
+        self.arena = arena
+        self._anchor = None
+        self._grad_views = {n: arena.g(n) for n, _ in named}
+        self._after_pack()
+
+    def _apply(self, fn, *args, **kwargs):
+        super()._apply(fn, *args, **kwargs)
+        dev = next(self.parameters()).device
+        aliased = all(p.data_ptr() == self.arena.p(n).data_ptr() for n, p in self._named_trainable())
+        if not aliased or dev != self.arena.device:
+            self._pack(dev)
+        return self
+
+    def _G(self, prefix: str):
+        return lambda name: self._grad_views[prefix + name]
+
+    def _expose_grads(self):
+        for n, p in self._named_trainable():
+            p.grad = self._grad_views[n]
+
+    def set_distributed(self, world_size: int, rank: int = 0):
+        self.world_size, self.rank = int(world_size), int(rank)
+        self.som_layer._world_size = int(world_size)
+
+    def _overlap_enabled(self) -> bool:
+        import os
+        return self.world_size > 1 and os.environ.get("VSOM_OVERLAP_ALLREDUCE", "1") != "0"
+
+    def _start_prototype_allreduce(self):
+        """Called inside the backward pass right after the SOM backward: the [K, L] prototype
+        gradient (the bulk of the exchange: 79 MB of 100 MB at CIFAR shapes) is final, while the
+        whole encoder backward is still to run -- start its all-reduce now (RCCL runs it on its own
+        stream, ordered after the kernels already queued) and let it finish under those kernels."""
+        self._early = None
+        if not self._overlap_enabled():
+            return
+        import torch.distributed as dist
+        g = self.arena.grads
+        off, n, _ = self.arena.offsets["som_layer.prototypes"]
+        piece = g[off:off + n]
+        if g.is_cuda and dist.get_backend() == "gloo":
+            return                                   # CPU rehearsal backend: exchanged with the rest, staged through the host
+        self._early = (off, n, dist.all_reduce(piece, op=dist.ReduceOp.SUM, async_op=True))
+
+    def allreduce_gradients(self):
+        """Sum the gradient arena (ViT grads + prototype accumulators) across ranks (RCCL over xGMI
+        under the "nccl" backend); AdamW divides by world_size.  The prototype slice may already be
+        in flight (see _start_prototype_allreduce); the rest goes in one call per contiguous piece.
+        Under the gloo backend (CPU rehearsal of the N > 1 path) device tensors are staged through
+        the host."""
+        if self.world_size <= 1 or self._grads_reduced:
+            return
+        self._grads_reduced = True            # idempotent until the next backward pass
+        import torch.distributed as dist
+        g = self.arena.grads
+        early, self._early = getattr(self, "_early", None), None
+        if g.is_cuda and dist.get_backend() == "gloo":
+            host = g.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM)
+            g.copy_(host)
+            return
+        if early is None:
+            dist.all_reduce(g, op=dist.ReduceOp.SUM)
+            return
+        off, n, work = early
+        if off > 0:
+            dist.all_reduce(g[:off], op=dist.ReduceOp.SUM)
+        if off + n < g.numel():
+            dist.all_reduce(g[off + n:], op=dist.ReduceOp.SUM)
+        work.wait()                            # the consumer stream now waits for the early piece
+
+
+
 # ------------------------------------------------------------------------------------ ViT-SOM
-class ViTSOM(_Base):
+class ViTSOM(_ArenaOwner, _Base):
     """Vision Transformer Self-Organizing Map (models/vit_som.py:17-187), MI355X-native."""
 
     def __init__(self, config, device=None):
@@ -661,41 +777,16 @@ class ViTSOM(_Base):
         self._pack(torch.device(device))
 
     # -- arenas -------------------------------------------------------------------------------
-    def _named_trainable(self):
-        return [(n, p) for n, p in self.named_parameters() if p.requires_grad]
+    def _default_weight_decay(self, name: str, p) -> float:
+        if name.startswith("vit."):
+            return 0.0 if p.ndim == 1 else 0.05
+        return 0.01
+
+    def _after_pack(self):
+        self._build_weight_transposes()
 
     def _decoder_param_names(self):
         return [n for n, _ in self._named_trainable() if n.startswith("vit.decoder_")]
-
-    def _pack(self, device):
-        """(Re)build the flat arenas on `device` and re-point every Parameter at its view."""
-        old_wd = self.arena.wd_by_name if self.arena is not None else {}
-        named = self._named_trainable()
-        specs = []
-        for n, p in named:
-            if n in old_wd:
-                wd = old_wd[n]
-            elif n.startswith("vit."):
-                wd = 0.0 if p.ndim == 1 else 0.05
-            else:
-                wd = 0.01
-            specs.append((n, tuple(p.shape), wd))
-        arena = ParamArena(specs, device)
-        with torch.no_grad():
-            for n, p in named:
-                v = arena.p(n)
-                v.copy_(p.detach().to(device))
-                p.data = v
-            for n, b in list(self.named_buffers()) + [(n, p) for n, p in self.named_parameters() if not p.requires_grad]:
-                if b.device != device:
-                    b.data = b.data.to(device)
-        if self.arena is not None and self.arena.device == device:
-            arena.exp_avg.copy_(self.arena.exp_avg)
-            arena.exp_avg_sq.copy_(self.arena.exp_avg_sq)
-        self.arena = arena
-        self._anchor = None
-        self._grad_views = {n: arena.g(n) for n, _ in named}
-        self._build_weight_transposes()
 
     def _build_weight_transposes(self):
         """Transposed copies W^T of the ViT Linear weights whose input gradient is needed, so that
@@ -725,31 +816,12 @@ class ViTSOM(_Base):
     def _WT(self, weight):
         return self._wt_views.get(weight.data_ptr())
 
-    def _apply(self, fn, *args, **kwargs):
-        super()._apply(fn, *args, **kwargs)
-        dev = next(self.parameters()).device
-        aliased = all(p.data_ptr() == self.arena.p(n).data_ptr() for n, p in self._named_trainable())
-        if not aliased or dev != self.arena.device:
-            self._pack(dev)
-        return self
-
-    def _G(self, prefix: str):
-        return lambda name: self._grad_views[prefix + name]
-
-    def _expose_grads(self):
-        for n, p in self._named_trainable():
-            p.grad = self._grad_views[n]
-
     # -- schedules ----------------------------------------------------------------------------
     def set_schedule(self, n_train: int, estimated_stepping_batches: int):
         """Trainer-less replacement for len(trainer.train_dataloader.dataset) and
         trainer.estimated_stepping_batches (som_layer.py:131, vit_som.py:89)."""
         self._n_train, self._est_steps = int(n_train), int(estimated_stepping_batches)
         self.som_layer._n_train = int(n_train)
-
-    def set_distributed(self, world_size: int, rank: int = 0):
-        self.world_size, self.rank = int(world_size), int(rank)
-        self.som_layer._world_size = int(world_size)
 
     def _estimated_steps(self) -> int:
         if self._est_steps is not None:
@@ -888,53 +960,6 @@ class ViTSOM(_Base):
         self.vit._encoder_bwd(a, Gv, self._WT)
 
     # -- data-parallel exchange ----------------------------------------------------------------
-    def _overlap_enabled(self) -> bool:
-        import os
-        return self.world_size > 1 and os.environ.get("VSOM_OVERLAP_ALLREDUCE", "1") != "0"
-
-    def _start_prototype_allreduce(self):
-        """Called inside the backward pass right after the SOM backward: the [K, L] prototype
-        gradient (the bulk of the exchange: 79 MB of 100 MB at CIFAR shapes) is final, while the
-        whole encoder backward is still to run -- start its all-reduce now (RCCL runs it on its own
-        stream, ordered after the kernels already queued) and let it finish under those kernels."""
-        self._early = None
-        if not self._overlap_enabled():
-            return
-        import torch.distributed as dist
-        g = self.arena.grads
-        off, n, _ = self.arena.offsets["som_layer.prototypes"]
-        piece = g[off:off + n]
-        if g.is_cuda and dist.get_backend() == "gloo":
-            return                                   # CPU rehearsal backend: exchanged with the rest, staged through the host
-        self._early = (off, n, dist.all_reduce(piece, op=dist.ReduceOp.SUM, async_op=True))
-
-    def allreduce_gradients(self):
-        """Sum the gradient arena (ViT grads + prototype accumulators) across ranks (RCCL over xGMI
-        under the "nccl" backend); AdamW divides by world_size.  The prototype slice may already be
-        in flight (see _start_prototype_allreduce); the rest goes in one call per contiguous piece.
-        Under the gloo backend (CPU rehearsal of the N > 1 path) device tensors are staged through
-        the host."""
-        if self.world_size <= 1 or self._grads_reduced:
-            return
-        self._grads_reduced = True            # idempotent until the next backward pass
-        import torch.distributed as dist
-        g = self.arena.grads
-        early, self._early = getattr(self, "_early", None), None
-        if g.is_cuda and dist.get_backend() == "gloo":
-            host = g.cpu()
-            dist.all_reduce(host, op=dist.ReduceOp.SUM)
-            g.copy_(host)
-            return
-        if early is None:
-            dist.all_reduce(g, op=dist.ReduceOp.SUM)
-            return
-        off, n, work = early
-        if off > 0:
-            dist.all_reduce(g[:off], op=dist.ReduceOp.SUM)
-        if off + n < g.numel():
-            dist.all_reduce(g[off + n:], op=dist.ReduceOp.SUM)
-        work.wait()                            # the consumer stream now waits for the early piece
-
     # -- reference API ---------------------------------------------------------------------------
     def _schedules_for_step(self):
         self.som_layer.update_temperature(self._it)                     # vit_som.py:84 (iteration BEFORE increment)

@@ -84,6 +84,29 @@ def linear_gelu_fwd(x, W, bias, grad, act):
     return pre, act
 
 
+def linear_relu_fwd(x, W, bias, ygrad, yact):
+    """yact = relu(x W^T + b); ygrad = 1.0 where the pre-activation is positive (its derivative)."""
+    M, K = x.shape
+    N = W.shape[0]
+    _f32(x, "x"); _f32(W, "W"); _f32(ygrad, "ygrad"); _f32(yact, "yact")
+    assert W.is_contiguous() and W.shape[1] == K and ygrad.is_contiguous() and yact.is_contiguous()
+    assert ygrad.shape == (M, N) and yact.shape == (M, N)
+    check(lib.vsom_linear_relu_fwd(ptr(x), _rows(x), ptr(W), ptr(bias), ptr(ygrad), ptr(yact), M, N, K, stream()),
+          "vsom_linear_relu_fwd")
+    return yact
+
+
+def l1_loss(pred, target, loss_sum, dpred=None, grad_scale=0.0):
+    """loss_sum[0] = sum |pred - target|; dpred = grad_scale * sign(pred - target)."""
+    assert pred.is_contiguous() and target.is_contiguous() and pred.numel() == target.numel()
+    _f32(pred, "pred"); _f32(target, "target")
+    n = pred.numel()
+    ws = scratch(lib.vsom_l1_loss_workspace_bytes(n), pred.device)
+    check(lib.vsom_l1_loss(ptr(pred), ptr(target), ptr(loss_sum), ptr(dpred), float(grad_scale), n, ptr(ws), ws.numel(),
+                           stream()), "vsom_l1_loss")
+    return loss_sum
+
+
 def linear_residual_fwd(x, W, bias, R, r_mod, out):
     M, K = x.shape
     N = W.shape[0]
