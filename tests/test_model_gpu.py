@@ -191,6 +191,32 @@ def test_steps_are_deterministic():
     assert torch.equal(outs[0], outs[1])
 
 
+def test_side_stream_weight_gradients_are_bitwise_identical(monkeypatch):
+    """The weight-gradient GEMMs run on a side stream (model.py: ViTAutoencoder._dw).  Arithmetic and
+    summation order are unchanged, so 8 training steps at CIFAR layer shapes must end in bit-identical
+    parameters with the side stream on and off -- any missed ordering edge would show up here."""
+    import vit_som_amd
+    from oracle.gen_golden import make_config
+    cfg = make_config(3, 32, 4, 192, 4, 3, 96, 2, (12, 12), 0, 96)
+    finals = []
+    for side in ("0", "1"):
+        monkeypatch.setenv("VSOM_SIDE_STREAM", side)
+        torch.manual_seed(0)
+        m = vit_som_amd.ViTSOM(copy.deepcopy(cfg), device=DEV)
+        m.set_schedule(5000, 500)
+        m._it = 100
+        (opt,), _ = m.configure_optimizers()
+        g = torch.Generator().manual_seed(5)
+        for _ in range(8):
+            x = torch.randn(96, 3, 32, 32, generator=g).to(DEV)
+            y = torch.zeros(96, dtype=torch.int64, device=DEV)
+            m.train_step_fused(x, y)
+            opt.step()
+        assert (m.vit._side is not None) == (side == "1")
+        finals.append(m.arena.params.clone())
+    assert torch.equal(finals[0], finals[1])
+
+
 def test_use_reduced_cls_token_som():
     """use_reduced=True: SOM on the CLS token (L = E), vit_som.py:70-71."""
     from oracle import vitsom_oracle as O

@@ -310,26 +310,59 @@ class ViTAutoencoder(nn.Module):
             return ops.linear_bwd_input_t(dy, wt, dx, **kw)
         return ops.linear_bwd_input(dy, weight, dx, **kw)
 
+    # Weight-gradient GEMMs (and their slab reductions) are off the backward's critical path: nothing
+    # reads dW before the optimizer.  With a side stream set (ViTSOM does, on the GPU) they run
+    # concurrently with the dX / LayerNorm / attention chain and fill its tail rounds and the
+    # small-grid gaps.  Ordering: (1) a side GEMM waits for the main-stream kernel that produced
+    # its dY; (2) the dY buffers (gout / dh / g1 / dqkv) are only rewritten in the NEXT block, whose
+    # entry waits for the side work of this one (_side_join); (3) the owner joins the side stream
+    # before anything reads the gradients.  The saved activations the GEMMs read are not written
+    # during a backward pass.
+    _side = None
+    _side_done = None
+
+    def _dw(self, dy, x, gw, gb):
+        side = self._side
+        if side is None:
+            return ops.linear_bwd_weight(dy, x, gw, gb)
+        ev = torch.cuda.Event()
+        ev.record()
+        with torch.cuda.stream(side):
+            side.wait_event(ev)
+            ops.linear_bwd_weight(dy, x, gw, gb)
+
+    def _side_join(self):
+        """Main stream waits for the side work of the previous block (before its dY buffers are reused)."""
+        if self._side is not None and self._side_done is not None:
+            torch.cuda.current_stream().wait_event(self._side_done)
+            self._side_done = None
+
+    def _side_mark(self):
+        if self._side is not None:
+            self._side_done = self._side.record_event()
+
     def _block_bwd(self, blk: Block, L: _Acts, x_in, gout, a: _Acts, G, prefix: str, bufs, WT=None):
         """gout: gradient w.r.t. the block output [T,dim]; returns gradient w.r.t. x_in (in bufs)."""
         T, dim, hid = a.T, blk.dim, blk.hidden
+        self._side_join()
         g1, g0 = bufs
         dh = a.dh[:T * hid].view(T, hid)
         da = a.da[:T * dim].view(T, dim)
         dqkv = a.dqkv[:T * 3 * dim].view(T, 3 * dim)
-        ops.linear_bwd_weight(gout, L.hact, G(f"{prefix}.mlp.2.weight"), G(f"{prefix}.mlp.2.bias"))
+        self._dw(gout, L.hact, G(f"{prefix}.mlp.2.weight"), G(f"{prefix}.mlp.2.bias"))
         self._dx(WT, gout, blk.mlp["2"].weight, dh, gelu_grad=L.hpre)
-        ops.linear_bwd_weight(dh, L.a2, G(f"{prefix}.mlp.0.weight"), G(f"{prefix}.mlp.0.bias"))
+        self._dw(dh, L.a2, G(f"{prefix}.mlp.0.weight"), G(f"{prefix}.mlp.0.bias"))
         self._dx(WT, dh, blk.mlp["0"].weight, da)
         ops.layernorm_bwd(da, L.x1, L.mean2, L.rstd2, blk.norm2.weight, gout, g1, G(f"{prefix}.norm2.weight"),
                           G(f"{prefix}.norm2.bias"))
-        ops.linear_bwd_weight(g1, L.ao, G(f"{prefix}.attn.proj.weight"), G(f"{prefix}.attn.proj.bias"))
+        self._dw(g1, L.ao, G(f"{prefix}.attn.proj.weight"), G(f"{prefix}.attn.proj.bias"))
         self._dx(WT, g1, blk.attn.proj.weight, da)
         ops.attention_bwd(L.qkv, L.ao, da, L.lse, dqkv, a.delta, a.B, a.N, blk.heads, dim // blk.heads)
-        ops.linear_bwd_weight(dqkv, L.a1, G(f"{prefix}.attn.qkv.weight"), G(f"{prefix}.attn.qkv.bias"))
+        self._dw(dqkv, L.a1, G(f"{prefix}.attn.qkv.weight"), G(f"{prefix}.attn.qkv.bias"))
         self._dx(WT, dqkv, blk.attn.qkv.weight, da)
         ops.layernorm_bwd(da, x_in, L.mean1, L.rstd1, blk.norm1.weight, g1, g0, G(f"{prefix}.norm1.weight"),
                           G(f"{prefix}.norm1.bias"))
+        self._side_mark()
         return g0
 
     def _views(self, a: _Acts, dim: int):
@@ -356,6 +389,7 @@ class ViTAutoencoder(nn.Module):
 
     def _encoder_bwd(self, a: _Acts, G, WT=None):
         """a.d_xe holds dL/d(xe); writes every encoder gradient."""
+        self._side_join()                  # the decoder's last block may still be reading the shared buffers
         E = self.embed_dim
         gA, gB, gC = self._views(a, E)
         x_last = a.enc[-1].x2 if a.enc else a.tok0
@@ -932,6 +966,12 @@ class ViTSOM(_ArenaOwner, _Base):
         x, a, s = self._ctx
         self._grads_reduced = False
         self._early = None
+        if x.is_cuda and os.environ.get("VSOM_SIDE_STREAM", "1") != "0":
+            if getattr(self, "_side_stream", None) is None or self._side_stream.device != x.device:
+                self._side_stream = torch.cuda.Stream(device=x.device)
+            self.vit._side = self._side_stream
+        else:
+            self.vit._side = None
         Gv = self._G("vit.")
         self._refresh_weight_transposes()
         if self.classification:
@@ -958,6 +998,9 @@ class ViTSOM(_ArenaOwner, _Base):
                         self._grad_views["som_layer.prototypes"], gX, accumulate_gx=True)
         self._start_prototype_allreduce()
         self.vit._encoder_bwd(a, Gv, self._WT)
+        if self.vit._side is not None:
+            torch.cuda.current_stream().wait_stream(self.vit._side)     # every gradient is final from here on
+            self.vit._side_done = None
 
     # -- data-parallel exchange ----------------------------------------------------------------
     # -- reference API ---------------------------------------------------------------------------

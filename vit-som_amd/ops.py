@@ -40,8 +40,9 @@ def reset_timer(name: str):
 
 
 def scratch(nbytes: int, device) -> torch.Tensor:
-    """Grow-only per-device byte scratch (stream-ordered reuse; 256-byte aligned by the allocator)."""
-    key = torch.device(device).index or 0
+    """Grow-only byte scratch per (device, stream): reuse is ordered by the stream the kernels run on
+    (256-byte aligned by the allocator)."""
+    key = (torch.device(device).index or 0, stream() if torch.device(device).type == "cuda" else 0)
     buf = _scratch.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
