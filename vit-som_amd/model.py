@@ -968,35 +968,59 @@ class ViTSOM(_ArenaOwner, _Base):
         self._early = None
         if x.is_cuda and os.environ.get("VSOM_SIDE_STREAM", "1") != "0":
             if getattr(self, "_side_stream", None) is None or self._side_stream.device != x.device:
-                self._side_stream = torch.cuda.Stream(device=x.device)
+                self._side_stream = torch.cuda.Stream(device=x.device)      # weight-gradient GEMMs
+                self._som_stream = torch.cuda.Stream(device=x.device)       # SOM backward + early all-reduce
             self.vit._side = self._side_stream
         else:
             self.vit._side = None
         Gv = self._G("vit.")
         self._refresh_weight_transposes()
-        if self.classification:
-            ops.fill(a.d_xe, 0.0)
-            # decoder is unused by the classification loss: its gradients are exactly zero
-            for n in self._decoder_param_names():
-                ops.fill(self._grad_views[n], 0.0)
-            ops.linear_bwd_weight(a.dlogits, self._cls_view(a.xe, a), self._grad_views["cls_head.weight"],
-                                  self._grad_views["cls_head.bias"])
-            ops.linear_bwd_input(a.dlogits, self.cls_head.weight, self._cls_view(a.d_xe, a), accumulate=True)
-        else:
-            self.vit._decoder_bwd(a, Gv, self._WT)
         X = self._som_input(a)
         E, N = self.vit.embed_dim, a.N
         if self.use_reduced:
             gX = torch.as_strided(a.d_xe, (a.B, E), (N * E, 1), a.d_xe.storage_offset())
         else:
             gX = torch.as_strided(a.d_xe, (a.B, (N - 1) * E), (N * E, 1), a.d_xe.storage_offset() + E)
-        if self.som_layer._dist_mode == ops.DIST_MANHATTAN:
-            ops.som_bwd_manhattan(X, self.som_layer.prototypes, s.coef, self._grad_views["som_layer.prototypes"], gX,
-                                  accumulate_gx=True)
+
+        def som_backward(gx_out, accumulate):
+            if self.som_layer._dist_mode == ops.DIST_MANHATTAN:
+                ops.som_bwd_manhattan(X, self.som_layer.prototypes, s.coef, self._grad_views["som_layer.prototypes"], gx_out,
+                                      accumulate_gx=accumulate)
+            else:
+                ops.som_bwd(X, self.som_layer.prototypes, s.coef, s.row_dot, s.col_dot,
+                            self._grad_views["som_layer.prototypes"], gx_out, accumulate_gx=accumulate)
+
+        side = self._som_stream if self.vit._side is not None else None
+        if self.classification or side is None:
+            if self.classification:
+                ops.fill(a.d_xe, 0.0)
+                # decoder is unused by the classification loss: its gradients are exactly zero
+                for n in self._decoder_param_names():
+                    ops.fill(self._grad_views[n], 0.0)
+                ops.linear_bwd_weight(a.dlogits, self._cls_view(a.xe, a), self._grad_views["cls_head.weight"],
+                                      self._grad_views["cls_head.bias"])
+                ops.linear_bwd_input(a.dlogits, self.cls_head.weight, self._cls_view(a.d_xe, a), accumulate=True)
+            else:
+                self.vit._decoder_bwd(a, Gv, self._WT)
+            som_backward(gX, True)
+            self._start_prototype_allreduce()
         else:
-            ops.som_bwd(X, self.som_layer.prototypes, s.coef, s.row_dot, s.col_dot,
-                        self._grad_views["som_layer.prototypes"], gX, accumulate_gx=True)
-        self._start_prototype_allreduce()
+            # The SOM backward depends only on the forward (coef, X, W), so it runs on a stream of its
+            # own under the decoder backward; its input gradient goes to a buffer of its own and is added
+            # to the decoder's once both are done.  The prototype all-reduce is issued from that
+            # stream too: it starts the moment gW is final, before the decoder backward has finished.
+            if getattr(a, "d_som", None) is None or a.d_som.shape != gX.shape:
+                a.d_som = torch.empty(gX.shape, dtype=torch.float32, device=gX.device)
+            ev = torch.cuda.Event()
+            ev.record()
+            with torch.cuda.stream(side):
+                side.wait_event(ev)
+                som_backward(a.d_som, False)
+                self._start_prototype_allreduce()
+                som_done = side.record_event()
+            self.vit._decoder_bwd(a, Gv, self._WT)
+            torch.cuda.current_stream().wait_event(som_done)
+            gX.add_(a.d_som)
         self.vit._encoder_bwd(a, Gv, self._WT)
         if self.vit._side is not None:
             torch.cuda.current_stream().wait_stream(self.vit._side)     # every gradient is final from here on
