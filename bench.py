@@ -104,8 +104,8 @@ def secondary_kernels(ops, B, dev):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=512, help="per-GPU batch (BASELINE c3: 512)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
