@@ -192,6 +192,58 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& g, const f32x16 (&acc
             const int mb = m0 + i * 32 + 4 * h;
             float bn = 0.f;
             if constexpr (EPI == EPI_BIAS || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RELU || EPI == EPI_BIAS_RES) bn = g.bias ? g.bias[n] : 0.f;
+            // Fast path: all 32 rows of this tile are inside the matrix (every tile of the step's
+            // GEMMs): no per-element guards, rows walked with running pointers (register v -> v+1 is
+            // the next row, every 4th step skips to the lane group's next 4-row band).
+            const bool plain_rows = (m0 + i * 32 + 31 < g.M) && !rowmap &&
+                                    !((EPI == EPI_BIAS_RES) && !(g.r_mod >= g.M && g.r_off == 0));
+            if (plain_rows) {
+                float* d = (EPI == EPI_SLAB) ? g.slab + (long)z * g.slab_stride + (long)mb * g.N + n : g.C + (long)mb * g.ldc + n;
+                const long dstep = (EPI == EPI_SLAB) ? (long)g.N : g.ldc;
+                const float* rp = nullptr;
+                float* d2 = nullptr;
+                if constexpr (EPI == EPI_ROWAXPY || EPI == EPI_GELU_BWD || EPI == EPI_BIAS_RES) rp = g.R + (long)mb * g.ldr + n;
+                if constexpr (EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RELU) d2 = g.C2 + (long)mb * g.ldc2 + n;
+                const float* rs = nullptr;
+                if constexpr (EPI == EPI_ROWAXPY) rs = g.rowscale + mb;
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const float a = acc[i][j][v];
+                    if constexpr (EPI == EPI_SLAB) {
+                        *d = a;
+                    } else if constexpr (EPI == EPI_NONE) {
+                        float val = g.alpha * a;
+                        if (g.accumulate) val += *d;
+                        *d = val;
+                    } else if constexpr (EPI == EPI_BIAS) {
+                        *d = a + bn;
+                    } else if constexpr (EPI == EPI_BIAS_GELU) {
+                        float act, grad;
+                        gelu_erf_both(a + bn, act, grad);
+                        *d = grad;
+                        *d2 = act;
+                    } else if constexpr (EPI == EPI_BIAS_RELU) {
+                        const float pre = a + bn;
+                        *d = pre > 0.f ? 1.0f : 0.f;
+                        *d2 = fmaxf(pre, 0.f);
+                    } else if constexpr (EPI == EPI_BIAS_RES) {
+                        *d = a + bn + *rp;
+                    } else if constexpr (EPI == EPI_ROWAXPY) {
+                        float val = a + rs[(v & 3) + 8 * (v >> 2)] * *rp;
+                        if (g.accumulate) val += *d;
+                        *d = val;
+                    } else if constexpr (EPI == EPI_GELU_BWD) {
+                        float val = a * *rp;
+                        if (g.accumulate) val += *d;
+                        *d = val;
+                    }
+                    const long adv = ((v & 3) == 3) ? 5 : 1;          // rows (v&3) + 8 (v>>2): +1, +1, +1, +5
+                    d += adv * dstep;
+                    if constexpr (EPI == EPI_ROWAXPY || EPI == EPI_GELU_BWD || EPI == EPI_BIAS_RES) rp += adv * g.ldr;
+                    if constexpr (EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RELU) d2 += adv * g.ldc2;
+                }
+                continue;
+            }
             if constexpr (EPI == EPI_SLAB) {
                 float* dst = g.slab + (long)z * g.slab_stride + (long)mb * g.N + n;
 #pragma unroll
