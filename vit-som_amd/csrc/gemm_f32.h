@@ -390,17 +390,13 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmP g) {
     }
     __syncthreads();
 
-    for (int kt = kt_begin; kt < kt_end; ++kt) {
-        const bool more = (kt + 1 < kt_end);
-        if (more) gload(kt + 1);               // global loads stay in flight under the MFMAs
-
+    auto mfma_tile = [&]() {
         if (want_colsum && t < BM) {
             float s = 0.f;
 #pragma unroll
             for (int kk = 0; kk < 32; ++kk) s += As[kk * (BM + 4) + t];
             colsum += s;
         }
-
 #pragma unroll
         for (int kb = 0; kb < 32; kb += 8) {
             f32x4 a[WM], b[WN];
@@ -430,12 +426,18 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmP g) {
                     for (int j = 0; j < WN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
         }
+    };
+    // Branch-free steady-state body with the last k-tile peeled: a conditional prefetch inside the
+    // loop makes hipcc carry the accumulators through VGPRs (all of them copied AGPR -> VGPR ->
+    // AGPR every iteration).  The next tile's global loads stay in flight under the MFMAs.
+    for (int kt = kt_begin; kt + 1 < kt_end; ++kt) {
+        gload(kt + 1);
+        mfma_tile();
         __syncthreads();
-        if (more) {
-            lstore();
-            __syncthreads();
-        }
+        lstore();
+        __syncthreads();
     }
+    if (kt_begin < kt_end) mfma_tile();
 
     if constexpr (EPI == EPI_SLAB) {
         if (want_colsum && t < BM && bm0 + t < g.M) g.slab_bias[(long)z * g.slab_bias_stride + bm0 + t] = colsum;

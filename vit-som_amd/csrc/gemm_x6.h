@@ -175,9 +175,7 @@ __global__ __launch_bounds__(256) void gemm_x6_kernel(const GemmP g) {
     }
     __syncthreads();
 
-    for (int kt = kt_begin; kt < kt_end; ++kt) {
-        const bool more = (kt + 1 < kt_end);
-        if (more) gload(kt + 1);
+    auto mfma_tile = [&]() {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             bf16x8 a[WM][3], b[WN][3];
@@ -205,12 +203,18 @@ __global__ __launch_bounds__(256) void gemm_x6_kernel(const GemmP g) {
                     acc[i][j] = c;
                 }
         }
+    };
+    // The steady-state loop body is branch-free (the last k-tile is peeled): with a conditional
+    // prefetch inside, hipcc carries the accumulators through VGPRs and copies all of them
+    // AGPR -> VGPR -> AGPR on every iteration.
+    for (int kt = kt_begin; kt + 1 < kt_end; ++kt) {
+        gload(kt + 1);
+        mfma_tile();
         __syncthreads();
-        if (more) {
-            lstore();
-            __syncthreads();
-        }
+        lstore();
+        __syncthreads();
     }
+    if (kt_begin < kt_end) mfma_tile();
     if constexpr (EPI == EPI_SLAB && !A_KC) {
         if (want_colsum && has_a) {              // the 8 k-groups of a column quad are 8 consecutive lanes
 #pragma unroll
