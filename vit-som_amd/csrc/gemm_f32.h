@@ -432,6 +432,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmP g) {
     // AGPR every iteration).  The next tile's global loads stay in flight under the MFMAs.
     for (int kt = kt_begin; kt + 1 < kt_end; ++kt) {
         gload(kt + 1);
+        __builtin_amdgcn_sched_barrier(0);      // keep the loads ABOVE the MFMAs (the scheduler otherwise sinks them to their use)
         mfma_tile();
         __syncthreads();
         lstore();
