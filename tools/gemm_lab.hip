@@ -399,10 +399,11 @@ void run_x6(const char* tag, const float* A, const float* B, float* C, float* Cr
     printf("%-22s tile %dx%d occ %d: %7.1f us  %6.1f TF(f32-equiv)  rel err vs fp64: x6 %.2e, exact-f32 %.2e\n", tag, BM, BN, OCC, best * 1e3, 2.0 * M * N * K / best / 1e9, sqrt(e6 / nrm), sqrt(e32 / nrm));
 }
 
-int main() {
-    const int M = 33280, N = 576, K = 192;
+int main(int argc, char** argv) {
+    const int M = argc > 1 ? atoi(argv[1]) : 33280, N = argc > 2 ? atoi(argv[2]) : 576, K = argc > 3 ? atoi(argv[3]) : 192;
+    const bool only_f32 = argc > 4;
     float *A, *B, *C; hipMalloc(&A, (size_t)M * K * 4); hipMalloc(&B, (size_t)N * K * 4); hipMalloc(&C, (size_t)M * N * 4);
-    std::vector<float> h((size_t)M * K); for (size_t i = 0; i < h.size(); ++i) h[i] = (float)(((i * 2654435761u) >> 8) & 0xffff) / 65536.f - 0.5f;
+    std::vector<float> h((size_t)(M > N ? M : N) * K); for (size_t i = 0; i < h.size(); ++i) h[i] = (float)(((i * 2654435761u) >> 8) & 0xffff) / 65536.f - 0.5f;
     hipMemcpy(A, h.data(), h.size() * 4, hipMemcpyHostToDevice); hipMemcpy(B, h.data(), (size_t)N * K * 4, hipMemcpyHostToDevice);
     run<1, 2, 4, 1, 0, 1>("mfma only", A, B, C, M, N, K);
     run<1, 2, 4, 1, 4, 1>("+lds reads", A, B, C, M, N, K);
@@ -412,6 +413,7 @@ int main() {
     run<1, 2, 4, 1, 8, 1>("mfma+epilogue", A, B, C, M, N, K);
     float* C2; hipMalloc(&C2, (size_t)M * N * 4);
     run<1, 2, 4, 1, 15, 1>("full (reference out)", A, B, C2, M, N, K);
+    if (only_f32) return 0;
     { std::vector<float> hB(h.begin(), h.begin() + (size_t)N * K);
       run_x6<1, 2, 4, 1, 1>("bf16x6 split", A, B, C, C2, h, hB, M, N, K);
       run_x6<1, 2, 4, 1, 2>("bf16x6 split", A, B, C, C2, h, hB, M, N, K);
