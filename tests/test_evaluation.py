@@ -104,3 +104,31 @@ def test_evaluate_clustering_and_classification_against_oracle():
     bmu_fast, logits_fast = bmu_fast.clone(), logits_fast.clone()
     full = m(x0)
     assert torch.equal(full[4], bmu_fast) and torch.equal(full[2], logits_fast)
+
+
+@pytest.mark.gpu
+def test_evaluation_drives_the_desom_client():
+    """evaluate_clustering / evaluate_classification (evaluation.py:38-39,115-116) on DESOM: same
+    decoder-free predict() contract as ViTSOM; BMUs / predictions against the DESOM oracle."""
+    import vit_som_amd
+    from oracle import desom_oracle as D
+    from sklearn.metrics import accuracy_score, normalized_mutual_info_score
+    from vit_som_amd.evaluation import evaluate_classification, evaluate_clustering
+    z, cfg = load_golden("ref_desom_cls_tiny")
+    P = golden_params(z)
+    d = cfg["data"]
+    g = torch.Generator().manual_seed(4)
+    batches = _Loader((torch.rand(9, d["num_channels"], d["input_size"], d["input_size"], generator=g),
+                       torch.randint(0, d["num_classes"], (9,), generator=g)) for _ in range(5))
+    m = vit_som_amd.DESOM(copy.deepcopy(cfg), device="cuda:0")
+    m.load_state_dict(P)
+    bm, lg, ys = [], [], []
+    for x, y in batches:
+        logits, _, _, bmu = D.forward(P, cfg, x)
+        bm.append(bmu); lg.append(logits.argmax(1)); ys.append(y)
+    bm, lg, ys = torch.cat(bm).numpy(), torch.cat(lg).numpy(), torch.cat(ys).numpy()
+    purity, nmi, _ = evaluate_clustering(m, cfg, batches)
+    assert abs(purity - purity_reference_loop(ys, bm)[0]) < 1e-12
+    assert abs(nmi - normalized_mutual_info_score(ys, bm)) < 1e-10
+    acc, *_ = evaluate_classification(m, cfg, batches)
+    assert abs(acc - accuracy_score(ys, lg)) < 1e-12

@@ -161,6 +161,20 @@ class DESOM(_ArenaOwner, _Base):
         return logits, z.clone(), dist, bmu
 
     @torch.no_grad()
+    def predict(self, x):
+        """Inference fast path for tools/evaluation.py (evaluate_clustering / evaluate_classification read
+        only the BMU indices / logits, evaluation.py:38-39,115-116): encoder + SOM (+ classifier), no
+        decoder.  Returns (bmu_indices [B] int64, logits [B,C] | None) as views of internal buffers."""
+        x = self._check_input(x)
+        a = self._buffers_for(x.shape[0], x.device)
+        s = self.som_layer._buffers_for(x.shape[0], x.device)
+        z = self._mlp_fwd(self.autoencoder.encoder, x, a.enc_act, a.enc_der)
+        self.som_layer._distances_into(z, s)
+        if self.classification:
+            ops.linear_fwd(z, self.classifier.weight, self.classifier.bias, a.logits)
+        return s.bmu, (a.logits if self.classification else None)
+
+    @torch.no_grad()
     def _forward_losses(self, x, y, gamma_t, T, want_grad: bool):
         """All forward kernels + losses (+ the loss-side gradients when want_grad).  ``gamma_t`` is the
         constant gamma of desom.py:27 (DESOM has no ramp); returns the total loss tensor."""
