@@ -212,7 +212,7 @@ def test_patch_embed(ops, O, gemm_mode, B, C, S, p, E):
     assert rel_err(dc.cpu(), cl.grad.reshape(E)) < 1e-5
 
 
-@pytest.mark.parametrize("rows,cols", [(130, 192), (70, 96), (37, 16), (20, 4), (9, 768)])
+@pytest.mark.parametrize("rows,cols", [(130, 192), (70, 96), (37, 16), (20, 4), (9, 768), (4163, 192), (77, 64), (50, 128), (33, 256)])
 def test_layernorm(ops, rows, cols):
     x = rnd(rows, cols, seed=1) * 2 + 0.5
     g, b = 1 + 0.1 * rnd(cols, seed=2), 0.1 * rnd(cols, seed=3)

@@ -106,6 +106,120 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     }
 }
 
+// ---- 16-byte variants for rows of 64 * NCH floats (E = 192 -> NCH = 3): 16 lanes per row, 4 rows per
+// wave, each lane holds NCH float4 chunks (chunk j of lane l = columns 4 (l + 16 j) ..) -- four
+// times the bytes in flight per wave of the scalar kernels above.
+__device__ __forceinline__ float group16_sum(float v) {
+    v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 1, 64);
+    return v;
+}
+
+template <int NCH>
+__global__ __launch_bounds__(256) void layernorm_fwd_v4_kernel(const float* __restrict__ X, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, float* __restrict__ Y,
+                                                               float* __restrict__ mean, float* __restrict__ rstd, int rows,
+                                                               float eps) {
+    constexpr int cols = 64 * NCH;
+    const int sub = threadIdx.x & 15;
+    const int row = blockIdx.x * 16 + (threadIdx.x >> 4);
+    const bool ok = row < rows;
+    const f32x4* x = reinterpret_cast<const f32x4*>(X + (long)(ok ? row : 0) * cols);
+    f32x4 v[NCH];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        v[j] = x[sub + 16 * j];
+        s += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
+    }
+    const float mu = group16_sum(s) * (1.0f / cols);
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float d = v[j][e] - mu; q = fmaf(d, d, q); }
+    const float rs = rsqrtf(group16_sum(q) * (1.0f / cols) + eps);
+    if (!ok) return;
+    f32x4* y = reinterpret_cast<f32x4*>(Y + (long)row * cols);
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        const f32x4 g4 = reinterpret_cast<const f32x4*>(gamma)[sub + 16 * j];
+        const f32x4 b4 = reinterpret_cast<const f32x4*>(beta)[sub + 16 * j];
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (v[j][e] - mu) * rs * g4[e] + b4[e];
+        y[sub + 16 * j] = o;
+    }
+    if (sub == 0) { mean[row] = mu; rstd[row] = rs; }
+}
+
+template <int NCH>
+__global__ __launch_bounds__(256) void layernorm_bwd_v4_kernel(const float* __restrict__ dY, const float* __restrict__ X,
+                                                               const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                               const float* __restrict__ gamma, const float* __restrict__ resid,
+                                                               float* __restrict__ dX, float* __restrict__ part, int rows) {
+    constexpr int cols = 64 * NCH;
+    __shared__ __attribute__((aligned(16))) float sh[16 * 2 * cols];          // [row group][dgamma | dbeta][cols]
+    const int sub = threadIdx.x & 15, rg = threadIdx.x >> 4;
+    f32x4 gam[NCH], dg[NCH], db[NCH];
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        gam[j] = reinterpret_cast<const f32x4*>(gamma)[sub + 16 * j];
+        dg[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        db[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    for (int row0 = blockIdx.x * 16; row0 < rows; row0 += gridDim.x * 16) {
+        const int row = row0 + rg;
+        const bool ok = row < rows;
+        const long base = (long)(ok ? row : 0) * cols;
+        const float mu = mean[ok ? row : 0], rs = rstd[ok ? row : 0];
+        f32x4 xh[NCH], g[NCH];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            f32x4 d = reinterpret_cast<const f32x4*>(dY + base)[sub + 16 * j];
+            const f32x4 xv = reinterpret_cast<const f32x4*>(X + base)[sub + 16 * j];
+            if (!ok) d = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                xh[j][e] = (xv[e] - mu) * rs;
+                g[j][e] = d[e] * gam[j][e];
+                s1 += g[j][e];
+                s2 = fmaf(g[j][e], xh[j][e], s2);
+                dg[j][e] = fmaf(d[e], xh[j][e], dg[j][e]);
+                db[j][e] += d[e];
+            }
+        }
+        s1 = group16_sum(s1) * (1.0f / cols);
+        s2 = group16_sum(s2) * (1.0f / cols);
+        if (ok) {
+#pragma unroll
+            for (int j = 0; j < NCH; ++j) {
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = rs * (g[j][e] - s1 - xh[j][e] * s2);
+                if (resid) {
+                    const f32x4 rr = reinterpret_cast<const f32x4*>(resid + base)[sub + 16 * j];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] += rr[e];
+                }
+                reinterpret_cast<f32x4*>(dX + base)[sub + 16 * j] = o;
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        reinterpret_cast<f32x4*>(sh + (rg * 2 + 0) * cols)[sub + 16 * j] = dg[j];
+        reinterpret_cast<f32x4*>(sh + (rg * 2 + 1) * cols)[sub + 16 * j] = db[j];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < 2 * cols; c += 256) {          // fixed order over the 16 row groups
+        float s = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) s += sh[q * 2 * cols + c];
+        part[(long)blockIdx.x * 2 * cols + c] = s;
+    }
+}
+
 static int ln_bwd_blocks(int rows) {
     int b = cdiv(rows, 16);          // ~4 rows per wave: 8 workgroups per CU keep enough loads in flight
     if (b > 2048) b = 2048;
@@ -125,6 +239,16 @@ int vsom_layernorm_fwd(const float* X, const float* gamma, const float* beta, fl
     VSOM_REQUIRE(rows > 0 && cols > 0, VSOM_EINVAL, "layernorm_fwd: bad shape");
     VSOM_REQUIRE(cols <= 1024, VSOM_EUNSUPPORTED, "layernorm_fwd: cols=%d > 1024", cols);
     dim3 grid(cdiv(rows, 4)), block(256);
+    if (cols % 64 == 0 && cols <= 256 && aligned16(X) && aligned16(Y) && aligned16(gamma) && aligned16(beta)) {
+        dim3 g16(cdiv(rows, 16));
+        switch (cols / 64) {
+            case 1: hipLaunchKernelGGL(layernorm_fwd_v4_kernel<1>, g16, block, 0, stream, X, gamma, beta, Y, mean, rstd, rows, eps); break;
+            case 2: hipLaunchKernelGGL(layernorm_fwd_v4_kernel<2>, g16, block, 0, stream, X, gamma, beta, Y, mean, rstd, rows, eps); break;
+            case 3: hipLaunchKernelGGL(layernorm_fwd_v4_kernel<3>, g16, block, 0, stream, X, gamma, beta, Y, mean, rstd, rows, eps); break;
+            default: hipLaunchKernelGGL(layernorm_fwd_v4_kernel<4>, g16, block, 0, stream, X, gamma, beta, Y, mean, rstd, rows, eps); break;
+        }
+        VSOM_LAUNCH_CHECK("layernorm_fwd_v4_kernel");
+    }
     if (cols <= 256)
         hipLaunchKernelGGL(layernorm_fwd_kernel<4>, grid, block, 0, stream, X, gamma, beta, Y, mean, rstd, rows, cols, eps);
     else
@@ -148,7 +272,16 @@ int vsom_layernorm_bwd(const float* dY, const float* X, const float* mean, const
     const int nblk = ln_bwd_blocks(rows);
     float* part = static_cast<float*>(ws);
     const size_t shmem = (size_t)8 * cols * sizeof(float);
-    if (cols <= 256)
+    const bool v4 = cols % 64 == 0 && cols <= 256 && aligned16(dY) && aligned16(X) && aligned16(gamma) && aligned16(dX) &&
+                    (!resid || aligned16(resid));
+    if (v4) {
+        switch (cols / 64) {
+            case 1: hipLaunchKernelGGL(layernorm_bwd_v4_kernel<1>, dim3(nblk), dim3(256), 0, stream, dY, X, mean, rstd, gamma, resid, dX, part, rows); break;
+            case 2: hipLaunchKernelGGL(layernorm_bwd_v4_kernel<2>, dim3(nblk), dim3(256), 0, stream, dY, X, mean, rstd, gamma, resid, dX, part, rows); break;
+            case 3: hipLaunchKernelGGL(layernorm_bwd_v4_kernel<3>, dim3(nblk), dim3(256), 0, stream, dY, X, mean, rstd, gamma, resid, dX, part, rows); break;
+            default: hipLaunchKernelGGL(layernorm_bwd_v4_kernel<4>, dim3(nblk), dim3(256), 0, stream, dY, X, mean, rstd, gamma, resid, dX, part, rows); break;
+        }
+    } else if (cols <= 256)
         hipLaunchKernelGGL(layernorm_bwd_kernel<4>, dim3(nblk), dim3(256), shmem, stream, dY, X, mean, rstd, gamma, resid, dX, part, rows, cols);
     else
         hipLaunchKernelGGL(layernorm_bwd_kernel<16>, dim3(nblk), dim3(256), shmem, stream, dY, X, mean, rstd, gamma, resid, dX, part, rows, cols);
