@@ -106,9 +106,10 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     }
 }
 
-// ---- 16-byte variants for rows of 64 * NCH floats (E = 192 -> NCH = 3): 16 lanes per row, 4 rows per
-// wave, each lane holds NCH float4 chunks (chunk j of lane l = columns 4 (l + 16 j) ..) -- four
-// times the bytes in flight per wave of the scalar kernels above.
+// ---- 16-byte variants for rows of cols <= 64 * NCH floats, cols % 4 == 0 (E = 192 -> NCH = 3, the
+// decoder's 96 -> NCH = 2 with half of the second chunk masked): 16 lanes per row, 4 rows per wave,
+// each lane holds NCH float4 chunks (chunk j of lane l = columns 4 (l + 16 j) ..) -- four times the
+// bytes in flight per wave of the scalar kernels above.
 __device__ __forceinline__ float group16_sum(float v) {
     v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 1, 64);
     return v;
@@ -118,30 +119,33 @@ template <int NCH>
 __global__ __launch_bounds__(256) void layernorm_fwd_v4_kernel(const float* __restrict__ X, const float* __restrict__ gamma,
                                                                const float* __restrict__ beta, float* __restrict__ Y,
                                                                float* __restrict__ mean, float* __restrict__ rstd, int rows,
-                                                               float eps) {
-    constexpr int cols = 64 * NCH;
+                                                               int cols, float eps) {
     const int sub = threadIdx.x & 15;
     const int row = blockIdx.x * 16 + (threadIdx.x >> 4);
     const bool ok = row < rows;
     const f32x4* x = reinterpret_cast<const f32x4*>(X + (long)(ok ? row : 0) * cols);
+    const float inv_n = 1.0f / (float)cols;
     f32x4 v[NCH];
+    bool cv[NCH];
     float s = 0.f;
 #pragma unroll
     for (int j = 0; j < NCH; ++j) {
-        v[j] = x[sub + 16 * j];
+        cv[j] = 4 * (sub + 16 * j) < cols;
+        v[j] = cv[j] ? x[sub + 16 * j] : f32x4{0.f, 0.f, 0.f, 0.f};
         s += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
     }
-    const float mu = group16_sum(s) * (1.0f / cols);
+    const float mu = group16_sum(s) * inv_n;
     float q = 0.f;
 #pragma unroll
     for (int j = 0; j < NCH; ++j)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { const float d = v[j][e] - mu; q = fmaf(d, d, q); }
-    const float rs = rsqrtf(group16_sum(q) * (1.0f / cols) + eps);
+        for (int e = 0; e < 4; ++e) { const float d = cv[j] ? v[j][e] - mu : 0.f; q = fmaf(d, d, q); }
+    const float rs = rsqrtf(group16_sum(q) * inv_n + eps);
     if (!ok) return;
     f32x4* y = reinterpret_cast<f32x4*>(Y + (long)row * cols);
 #pragma unroll
     for (int j = 0; j < NCH; ++j) {
+        if (!cv[j]) continue;
         const f32x4 g4 = reinterpret_cast<const f32x4*>(gamma)[sub + 16 * j];
         const f32x4 b4 = reinterpret_cast<const f32x4*>(beta)[sub + 16 * j];
         f32x4 o;
@@ -156,14 +160,17 @@ template <int NCH>
 __global__ __launch_bounds__(256) void layernorm_bwd_v4_kernel(const float* __restrict__ dY, const float* __restrict__ X,
                                                                const float* __restrict__ mean, const float* __restrict__ rstd,
                                                                const float* __restrict__ gamma, const float* __restrict__ resid,
-                                                               float* __restrict__ dX, float* __restrict__ part, int rows) {
-    constexpr int cols = 64 * NCH;
-    __shared__ __attribute__((aligned(16))) float sh[16 * 2 * cols];          // [row group][dgamma | dbeta][cols]
+                                                               float* __restrict__ dX, float* __restrict__ part, int rows,
+                                                               int cols) {
+    __shared__ __attribute__((aligned(16))) float sh[16 * 2 * 64 * NCH];      // [row group][dgamma | dbeta][cols]
     const int sub = threadIdx.x & 15, rg = threadIdx.x >> 4;
+    const float inv_n = 1.0f / (float)cols;
     f32x4 gam[NCH], dg[NCH], db[NCH];
+    bool cv[NCH];
 #pragma unroll
     for (int j = 0; j < NCH; ++j) {
-        gam[j] = reinterpret_cast<const f32x4*>(gamma)[sub + 16 * j];
+        cv[j] = 4 * (sub + 16 * j) < cols;
+        gam[j] = cv[j] ? reinterpret_cast<const f32x4*>(gamma)[sub + 16 * j] : f32x4{0.f, 0.f, 0.f, 0.f};
         dg[j] = f32x4{0.f, 0.f, 0.f, 0.f};
         db[j] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
@@ -176,9 +183,11 @@ __global__ __launch_bounds__(256) void layernorm_bwd_v4_kernel(const float* __re
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int j = 0; j < NCH; ++j) {
-            f32x4 d = reinterpret_cast<const f32x4*>(dY + base)[sub + 16 * j];
-            const f32x4 xv = reinterpret_cast<const f32x4*>(X + base)[sub + 16 * j];
-            if (!ok) d = f32x4{0.f, 0.f, 0.f, 0.f};
+            f32x4 d = f32x4{0.f, 0.f, 0.f, 0.f}, xv = f32x4{mu, mu, mu, mu};
+            if (cv[j]) {
+                xv = reinterpret_cast<const f32x4*>(X + base)[sub + 16 * j];
+                if (ok) d = reinterpret_cast<const f32x4*>(dY + base)[sub + 16 * j];
+            }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 xh[j][e] = (xv[e] - mu) * rs;
@@ -189,11 +198,12 @@ __global__ __launch_bounds__(256) void layernorm_bwd_v4_kernel(const float* __re
                 db[j][e] += d[e];
             }
         }
-        s1 = group16_sum(s1) * (1.0f / cols);
-        s2 = group16_sum(s2) * (1.0f / cols);
+        s1 = group16_sum(s1) * inv_n;
+        s2 = group16_sum(s2) * inv_n;
         if (ok) {
 #pragma unroll
             for (int j = 0; j < NCH; ++j) {
+                if (!cv[j]) continue;
                 f32x4 o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = rs * (g[j][e] - s1 - xh[j][e] * s2);
@@ -208,6 +218,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_v4_kernel(const float* __re
     }
 #pragma unroll
     for (int j = 0; j < NCH; ++j) {
+        if (!cv[j]) continue;
         reinterpret_cast<f32x4*>(sh + (rg * 2 + 0) * cols)[sub + 16 * j] = dg[j];
         reinterpret_cast<f32x4*>(sh + (rg * 2 + 1) * cols)[sub + 16 * j] = db[j];
     }
@@ -239,13 +250,13 @@ int vsom_layernorm_fwd(const float* X, const float* gamma, const float* beta, fl
     VSOM_REQUIRE(rows > 0 && cols > 0, VSOM_EINVAL, "layernorm_fwd: bad shape");
     VSOM_REQUIRE(cols <= 1024, VSOM_EUNSUPPORTED, "layernorm_fwd: cols=%d > 1024", cols);
     dim3 grid(cdiv(rows, 4)), block(256);
-    if (cols % 64 == 0 && cols <= 256 && aligned16(X) && aligned16(Y) && aligned16(gamma) && aligned16(beta)) {
+    if (cols % 4 == 0 && cols <= 256 && aligned16(X) && aligned16(Y) && aligned16(gamma) && aligned16(beta)) {
         dim3 g16(cdiv(rows, 16));
-        switch (cols / 64) {
-            case 1: hipLaunchKernelGGL(layernorm_fwd_v4_kernel<1>, g16, block, 0, stream, X, gamma, beta, Y, mean, rstd, rows, eps); break;
-            case 2: hipLaunchKernelGGL(layernorm_fwd_v4_kernel<2>, g16, block, 0, stream, X, gamma, beta, Y, mean, rstd, rows, eps); break;
-            case 3: hipLaunchKernelGGL(layernorm_fwd_v4_kernel<3>, g16, block, 0, stream, X, gamma, beta, Y, mean, rstd, rows, eps); break;
-            default: hipLaunchKernelGGL(layernorm_fwd_v4_kernel<4>, g16, block, 0, stream, X, gamma, beta, Y, mean, rstd, rows, eps); break;
+        switch ((cols + 63) / 64) {
+            case 1: hipLaunchKernelGGL(layernorm_fwd_v4_kernel<1>, g16, block, 0, stream, X, gamma, beta, Y, mean, rstd, rows, cols, eps); break;
+            case 2: hipLaunchKernelGGL(layernorm_fwd_v4_kernel<2>, g16, block, 0, stream, X, gamma, beta, Y, mean, rstd, rows, cols, eps); break;
+            case 3: hipLaunchKernelGGL(layernorm_fwd_v4_kernel<3>, g16, block, 0, stream, X, gamma, beta, Y, mean, rstd, rows, cols, eps); break;
+            default: hipLaunchKernelGGL(layernorm_fwd_v4_kernel<4>, g16, block, 0, stream, X, gamma, beta, Y, mean, rstd, rows, cols, eps); break;
         }
         VSOM_LAUNCH_CHECK("layernorm_fwd_v4_kernel");
     }
@@ -272,14 +283,14 @@ int vsom_layernorm_bwd(const float* dY, const float* X, const float* mean, const
     const int nblk = ln_bwd_blocks(rows);
     float* part = static_cast<float*>(ws);
     const size_t shmem = (size_t)8 * cols * sizeof(float);
-    const bool v4 = cols % 64 == 0 && cols <= 256 && aligned16(dY) && aligned16(X) && aligned16(gamma) && aligned16(dX) &&
+    const bool v4 = cols % 4 == 0 && cols <= 256 && aligned16(dY) && aligned16(X) && aligned16(gamma) && aligned16(dX) &&
                     (!resid || aligned16(resid));
     if (v4) {
-        switch (cols / 64) {
-            case 1: hipLaunchKernelGGL(layernorm_bwd_v4_kernel<1>, dim3(nblk), dim3(256), 0, stream, dY, X, mean, rstd, gamma, resid, dX, part, rows); break;
-            case 2: hipLaunchKernelGGL(layernorm_bwd_v4_kernel<2>, dim3(nblk), dim3(256), 0, stream, dY, X, mean, rstd, gamma, resid, dX, part, rows); break;
-            case 3: hipLaunchKernelGGL(layernorm_bwd_v4_kernel<3>, dim3(nblk), dim3(256), 0, stream, dY, X, mean, rstd, gamma, resid, dX, part, rows); break;
-            default: hipLaunchKernelGGL(layernorm_bwd_v4_kernel<4>, dim3(nblk), dim3(256), 0, stream, dY, X, mean, rstd, gamma, resid, dX, part, rows); break;
+        switch ((cols + 63) / 64) {
+            case 1: hipLaunchKernelGGL(layernorm_bwd_v4_kernel<1>, dim3(nblk), dim3(256), 0, stream, dY, X, mean, rstd, gamma, resid, dX, part, rows, cols); break;
+            case 2: hipLaunchKernelGGL(layernorm_bwd_v4_kernel<2>, dim3(nblk), dim3(256), 0, stream, dY, X, mean, rstd, gamma, resid, dX, part, rows, cols); break;
+            case 3: hipLaunchKernelGGL(layernorm_bwd_v4_kernel<3>, dim3(nblk), dim3(256), 0, stream, dY, X, mean, rstd, gamma, resid, dX, part, rows, cols); break;
+            default: hipLaunchKernelGGL(layernorm_bwd_v4_kernel<4>, dim3(nblk), dim3(256), 0, stream, dY, X, mean, rstd, gamma, resid, dX, part, rows, cols); break;
         }
     } else if (cols <= 256)
         hipLaunchKernelGGL(layernorm_bwd_kernel<4>, dim3(nblk), dim3(256), shmem, stream, dY, X, mean, rstd, gamma, resid, dX, part, rows, cols);
