@@ -71,6 +71,41 @@ __device__ __forceinline__ void stage_rows(float* lds, const float* __restrict__
         }
     }
 }
+// Two slices at once.  On the vector path every thread first ISSUES up to 4 + 4 sixteen-byte loads
+// and only then stores them: the one-slice loop above keeps a single load in flight per thread (load,
+// wait, store, next), i.e. four serialised global-memory latencies per slice at N = 65.
+template <int HDP>
+__device__ __forceinline__ void stage_rows_pair(float* ldsA, const float* __restrict__ srcA, long rsA, float* ldsB,
+                                                const float* __restrict__ srcB, long rsB, int N, int nrows, int hd) {
+    if constexpr (ACfg<HDP>::VEC) {
+        constexpr int S = ACfg<HDP>::S, C4 = HDP / 4;
+        const int total = nrows * C4, step = blockDim.x;
+        for (int base = threadIdx.x; base < total; base += 4 * step) {
+            f32x4 va[4], vb[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = base + u * step, row = idx / C4, c4 = idx % C4;
+                va[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                vb[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (idx < total && row < N) {
+                    va[u] = *reinterpret_cast<const f32x4*>(srcA + (long)row * rsA + 4 * c4);
+                    vb[u] = *reinterpret_cast<const f32x4*>(srcB + (long)row * rsB + 4 * c4);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = base + u * step, row = idx / C4, c4 = idx % C4;
+                if (idx < total) {
+                    *reinterpret_cast<f32x4*>(ldsA + row * S + 4 * c4) = va[u];
+                    *reinterpret_cast<f32x4*>(ldsB + row * S + 4 * c4) = vb[u];
+                }
+            }
+        }
+    } else {
+        stage_rows<HDP>(ldsA, srcA, rsA, N, nrows, hd);
+        stage_rows<HDP>(ldsB, srcB, rsB, N, nrows, hd);
+    }
+}
 // one row of hd floats -> lds[HDP] (zero padded)
 template <int HDP>
 __device__ __forceinline__ void stage_vec(float* lds, const float* __restrict__ src, int hd) {
@@ -288,8 +323,7 @@ __global__ __launch_bounds__(576) void attn_fwd_kernel(const float* __restrict__
     // the wave's first query fragment is requested BEFORE the K/V staging (latency overlaps it)
     float qf[ACfg<HDP>::NMM];
     if (!extra_wave) load_frag<HDP>(qf, base + (long)tok<EXTRA>(wave, r) * E3, qp, tok<EXTRA>(wave, r) < N, hd);
-    stage_rows<HDP>(Ks, base + E, E3, N, cv.nrows, hd);
-    stage_rows<HDP>(Vs, base + 2 * E, E3, N, cv.nrows, hd);
+    stage_rows_pair<HDP>(Ks, base + E, E3, Vs, base + 2 * E, E3, N, cv.nrows, hd);
     if (EXTRA) stage_vec<HDP>(cv.X0, base, hd);                       // q of token 0
     __syncthreads();
 
@@ -411,8 +445,7 @@ __global__ __launch_bounds__(576) void attn_bwd_dq_kernel(const float* __restric
         load_frag<HDP>(dof, dout + obase + (long)q0 * E, qp, q0 < N, hd);
         load_frag<HDP>(of, out + obase + (long)q0 * E, qp, q0 < N, hd);
     }
-    stage_rows<HDP>(Ks, base + E, E3, N, cv.nrows, hd);
-    stage_rows<HDP>(Vs, base + 2 * E, E3, N, cv.nrows, hd);
+    stage_rows_pair<HDP>(Ks, base + E, E3, Vs, base + 2 * E, E3, N, cv.nrows, hd);
     if (EXTRA) {
         stage_vec<HDP>(cv.X0, base, hd);                               // q of token 0
         stage_vec<HDP>(cv.X1, dout + obase, hd);                       // dO of token 0
@@ -513,8 +546,7 @@ __global__ __launch_bounds__(576) void attn_bwd_dkv_kernel(const float* __restri
         load_frag<HDP>(kf, base + (long)k0 * E3 + E, qp, k0 < N, hd);
         load_frag<HDP>(vf, base + (long)k0 * E3 + 2 * E, qp, k0 < N, hd);
     }
-    stage_rows<HDP>(Qs, base, E3, N, cv.nrows, hd);
-    stage_rows<HDP>(Ds, dout + (long)b * N * E + h * hd, E, N, cv.nrows, hd);
+    stage_rows_pair<HDP>(Qs, base, E3, Ds, dout + (long)b * N * E + h * hd, E, N, cv.nrows, hd);
     for (int i = threadIdx.x; i < cv.nrp; i += blockDim.x) {
         const long srow = ((long)b * H + h) * N + i;
         Ls[i] = (i < N) ? lse[srow] : 0.f;
