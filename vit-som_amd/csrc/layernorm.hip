@@ -232,8 +232,11 @@ __global__ __launch_bounds__(256) void layernorm_bwd_v4_kernel(const float* __re
 }
 
 static int ln_bwd_blocks(int rows) {
-    int b = cdiv(rows, 16);          // ~4 rows per wave: 8 workgroups per CU keep enough loads in flight
-    if (b > 2048) b = 2048;
+    // one partial [2][cols] per workgroup goes through the slab reducer afterwards (a handful of
+    // workgroups walking all partials): 512 workgroups of 4 x 16 rows keep ~9 KB of loads in flight per
+    // wave and leave the reducer a quarter of the partials 2048 single-pass workgroups would
+    int b = cdiv(rows, 16);
+    if (b > 512) b = 512;
     if (b < 1) b = 1;
     return b;
 }
