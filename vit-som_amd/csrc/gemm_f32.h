@@ -206,6 +206,23 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& g, const f32x16 (&acc
                 if constexpr (EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RELU) d2 = g.C2 + (long)mb * g.ldc2 + n;
                 const float* rs = nullptr;
                 if constexpr (EPI == EPI_ROWAXPY) rs = g.rowscale + mb;
+                // every input of the 16 rows is loaded BEFORE the first store: with loads and stores
+                // interleaved hipcc must assume aliasing and waits for each load (vmcnt(0)) before the next
+                // store -- 16 (or 32) serialised global-memory latencies per tile
+                constexpr bool READS_R = (EPI == EPI_ROWAXPY || EPI == EPI_GELU_BWD || EPI == EPI_BIAS_RES);
+                constexpr bool MAY_ACC = (EPI == EPI_NONE || EPI == EPI_ROWAXPY || EPI == EPI_GELU_BWD);
+                float rv[16], dv[16];
+                if constexpr (READS_R) {
+                    const float* q = rp;
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) { rv[v] = *q; q += (((v & 3) == 3) ? 5 : 1) * g.ldr; }
+                }
+                const bool accum = MAY_ACC && g.accumulate;
+                if (accum) {
+                    const float* q = d;
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) { dv[v] = *q; q += (((v & 3) == 3) ? 5 : 1) * dstep; }
+                }
 #pragma unroll
                 for (int v = 0; v < 16; ++v) {
                     const float a = acc[i][j][v];
@@ -213,7 +230,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& g, const f32x16 (&acc
                         *d = a;
                     } else if constexpr (EPI == EPI_NONE) {
                         float val = g.alpha * a;
-                        if (g.accumulate) val += *d;
+                        if (accum) val += dv[v];
                         *d = val;
                     } else if constexpr (EPI == EPI_BIAS) {
                         *d = a + bn;
@@ -227,19 +244,18 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& g, const f32x16 (&acc
                         *d = pre > 0.f ? 1.0f : 0.f;
                         *d2 = fmaxf(pre, 0.f);
                     } else if constexpr (EPI == EPI_BIAS_RES) {
-                        *d = a + bn + *rp;
+                        *d = a + bn + rv[v];
                     } else if constexpr (EPI == EPI_ROWAXPY) {
-                        float val = a + rs[(v & 3) + 8 * (v >> 2)] * *rp;
-                        if (g.accumulate) val += *d;
+                        float val = a + rs[(v & 3) + 8 * (v >> 2)] * rv[v];
+                        if (accum) val += dv[v];
                         *d = val;
                     } else if constexpr (EPI == EPI_GELU_BWD) {
-                        float val = a * *rp;
-                        if (g.accumulate) val += *d;
+                        float val = a * rv[v];
+                        if (accum) val += dv[v];
                         *d = val;
                     }
                     const long adv = ((v & 3) == 3) ? 5 : 1;          // rows (v&3) + 8 (v>>2): +1, +1, +1, +5
                     d += adv * dstep;
-                    if constexpr (EPI == EPI_ROWAXPY || EPI == EPI_GELU_BWD || EPI == EPI_BIAS_RES) rp += adv * g.ldr;
                     if constexpr (EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_RELU) d2 += adv * g.ldc2;
                 }
                 continue;
