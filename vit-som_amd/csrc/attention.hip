@@ -439,11 +439,13 @@ __global__ __launch_bounds__(576) void attn_bwd_dq_kernel(const float* __restric
     const bool extra_wave = EXTRA && wave == tile_waves;
     const int r = lane & 15, qp = lane >> 4;
     float qf[NMM], dof[NMM], of[NMM];
+    float lq_first = 0.f;                          // log-sum-exp of the wave's first query row, requested with the fragments
     if (!extra_wave) {
         const int q0 = tok<EXTRA>(wave, r);
         load_frag<HDP>(qf, base + (long)q0 * E3, qp, q0 < N, hd);
         load_frag<HDP>(dof, dout + obase + (long)q0 * E, qp, q0 < N, hd);
         load_frag<HDP>(of, out + obase + (long)q0 * E, qp, q0 < N, hd);
+        if (q0 < N) lq_first = lse[((long)b * H + h) * N + q0];
     }
     stage_rows_pair<HDP>(Ks, base + E, E3, Vs, base + 2 * E, E3, N, cv.nrows, hd);
     if (EXTRA) {
@@ -490,7 +492,7 @@ __global__ __launch_bounds__(576) void attn_bwd_dq_kernel(const float* __restric
         D = group_sum(D);
         const long srow = ((long)b * H + h) * N + query;
         if (qp == 0 && qok) delta[srow] = D;
-        const float lq = qok ? lse[srow] : 0.f;
+        const float lq = (qt == wave) ? lq_first : (qok ? lse[srow] : 0.f);
         f32x4 dq[NDT];
 #pragma unroll
         for (int dt = 0; dt < NDT; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -546,8 +548,17 @@ __global__ __launch_bounds__(576) void attn_bwd_dkv_kernel(const float* __restri
         load_frag<HDP>(kf, base + (long)k0 * E3 + E, qp, k0 < N, hd);
         load_frag<HDP>(vf, base + (long)k0 * E3 + 2 * E, qp, k0 < N, hd);
     }
+    // row statistics: the first blockDim rows are requested before the slice staging (one exposed
+    // global latency less), the rest (N > blockDim never happens for the supported shapes) after
+    const int i0 = threadIdx.x;
+    float l_r = 0.f, e_r = 0.f;
+    if (i0 < N) {
+        l_r = lse[((long)b * H + h) * N + i0];
+        e_r = delta[((long)b * H + h) * N + i0];
+    }
     stage_rows_pair<HDP>(Qs, base, E3, Ds, dout + (long)b * N * E + h * hd, E, N, cv.nrows, hd);
-    for (int i = threadIdx.x; i < cv.nrp; i += blockDim.x) {
+    if (i0 < cv.nrp) { Ls[i0] = l_r; Es[i0] = e_r; }
+    for (int i = threadIdx.x + blockDim.x; i < cv.nrp; i += blockDim.x) {
         const long srow = ((long)b * H + h) * N + i;
         Ls[i] = (i < N) ? lse[srow] : 0.f;
         Es[i] = (i < N) ? delta[srow] : 0.f;
