@@ -209,7 +209,9 @@ __global__ __launch_bounds__(256) void gemm_x6_kernel(const GemmP g) {
     // AGPR -> VGPR -> AGPR on every iteration.
     for (int kt = kt_begin; kt + 1 < kt_end; ++kt) {
         gload(kt + 1);
-        mfma_tile();
+        __builtin_amdgcn_sched_barrier(0);      // loads first, then the whole MFMA phase, and only then the split
+        mfma_tile();                            // (left alone, hipcc interleaves load -> vmcnt(0) -> split into the MFMAs)
+        __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
         lstore();
         __syncthreads();
