@@ -28,6 +28,32 @@ __global__ __launch_bounds__(256) void row_inv_norm_kernel(const float* __restri
     if (lane == 0) out[row] = squared ? s : 1.0f / fmaxf(sqrtf(s), eps);
 }
 
+// long rows (the SOM's L = 12288): one WORKGROUP per row, every thread's 16-byte loads issued up
+// front (a wave per row leaves a 512-row input on 128 workgroups with one load in flight per lane)
+__global__ __launch_bounds__(256) void row_inv_norm_wide_kernel(const float* __restrict__ X, long ldx, int cols, float eps,
+                                                                float* __restrict__ out, int squared) {
+    const f32x4* x = reinterpret_cast<const f32x4*>(X + (long)blockIdx.x * ldx);
+    const int n4 = cols >> 2;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int i = threadIdx.x;
+    for (; i + 768 < n4; i += 1024) {
+        const f32x4 a = x[i], b = x[i + 256], c = x[i + 512], d = x[i + 768];
+        s0 += (a[0] * a[0] + a[1] * a[1]) + (a[2] * a[2] + a[3] * a[3]);
+        s1 += (b[0] * b[0] + b[1] * b[1]) + (b[2] * b[2] + b[3] * b[3]);
+        s2 += (c[0] * c[0] + c[1] * c[1]) + (c[2] * c[2] + c[3] * c[3]);
+        s3 += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+    }
+    for (; i < n4; i += 256) { const f32x4 a = x[i]; s0 += (a[0] * a[0] + a[1] * a[1]) + (a[2] * a[2] + a[3] * a[3]); }
+    float s = wave_sum((s0 + s1) + (s2 + s3));
+    __shared__ float sh[4];
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        s = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+        out[blockIdx.x] = squared ? s : 1.0f / fmaxf(sqrtf(s), eps);
+    }
+}
+
 // ------------------------------------------------------------------ BMU finalize
 // dist[i,k] = 1 - (sum_s slab[s][i,k]) * inv_nx[i] * inv_nw[k];  bmu[i] = first argmin_k.
 // One workgroup per sample row; (value, index) reduction with lowest-index tie-break, so
@@ -41,14 +67,28 @@ __global__ __launch_bounds__(256) void bmu_finalize_kernel(const float* __restri
     const float rx = inv_nx ? inv_nx[i] : 0.f;   // cosine: 1/|x_i| ; euclidean: |x_i|^2 ; manhattan (euclid == 2): unused
     float best = INFINITY;
     int bidx = 0x7fffffff;
-    for (int k = threadIdx.x; k < K; k += 256) {
-        float dot = 0.f;
-        for (int s = 0; s < nslabs; ++s) dot += slab[(long)s * slab_stride + (long)i * K + k];
-        // euclidean: torch.cdist's matmul form  sqrt(clamp_min(|x|^2 + |w|^2 - 2 x.w, 1e-30))
-        const float d = euclid == 2 ? dot        // manhattan: the slabs already hold partial distances
-                      : euclid ? sqrtf(fmaxf(fmaf(-2.0f, dot, rx + inv_nw[k]), 1e-30f)) : 1.0f - dot * rx * inv_nw[k];
-        if (dist) dist[(long)i * K + k] = d;
-        if (d < best || (d == best && k < bidx)) { best = d; bidx = k; }
+    // four prototypes per thread and pass: their slab loads are independent and in flight together
+    // (one at a time, the nslabs x K/256 dependent loads of a thread are all serialised); the sum over
+    // the slabs of ONE (i, k) keeps its order s = 0, 1, ...
+    for (int k0 = threadIdx.x; k0 < K; k0 += 1024) {
+        float dot[4] = {0.f, 0.f, 0.f, 0.f};
+        const float* p = slab + (long)i * K + k0;
+        for (int s = 0; s < nslabs; ++s) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (k0 + 256 * u < K) dot[u] += p[256 * u];
+            p += slab_stride;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = k0 + 256 * u;
+            if (k >= K) break;
+            // euclidean: torch.cdist's matmul form  sqrt(clamp_min(|x|^2 + |w|^2 - 2 x.w, 1e-30))
+            const float d = euclid == 2 ? dot[u]      // manhattan: the slabs already hold partial distances
+                          : euclid ? sqrtf(fmaxf(fmaf(-2.0f, dot[u], rx + inv_nw[k]), 1e-30f)) : 1.0f - dot[u] * rx * inv_nw[k];
+            if (dist) dist[(long)i * K + k] = d;
+            if (d < best || (d == best && k < bidx)) { best = d; bidx = k; }
+        }
     }
     // NaN distances never win (d < best is false) unless every entry is NaN -> index 0x7fffffff
 #pragma unroll
@@ -183,6 +223,10 @@ int vsom_row_inv_norm(const float* X, long ldx, int rows, int cols, float eps, f
                       vsom_stream_t stream) {
     VSOM_REQUIRE(X && inv_norm && rows > 0 && cols > 0 && ldx >= cols, VSOM_EINVAL, "row_inv_norm: bad arguments");
     const int vec = aligned16(X) && (ldx % 4 == 0);
+    if (vec && cols % 4 == 0 && cols >= 4096) {
+        hipLaunchKernelGGL(row_inv_norm_wide_kernel, dim3(rows), dim3(256), 0, stream, X, ldx, cols, eps, inv_norm, 0);
+        VSOM_LAUNCH_CHECK("row_inv_norm_wide_kernel");
+    }
     hipLaunchKernelGGL(row_inv_norm_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, stream, X, ldx, rows, cols, eps,
                        inv_norm, vec, 0);
     VSOM_LAUNCH_CHECK("row_inv_norm_kernel");
@@ -191,6 +235,10 @@ int vsom_row_inv_norm(const float* X, long ldx, int rows, int cols, float eps, f
 int vsom_row_sqnorm(const float* X, long ldx, int rows, int cols, float* sqnorm, vsom_stream_t stream) {
     VSOM_REQUIRE(X && sqnorm && rows > 0 && cols > 0 && ldx >= cols, VSOM_EINVAL, "row_sqnorm: bad arguments");
     const int vec = aligned16(X) && (ldx % 4 == 0);
+    if (vec && cols % 4 == 0 && cols >= 4096) {
+        hipLaunchKernelGGL(row_inv_norm_wide_kernel, dim3(rows), dim3(256), 0, stream, X, ldx, cols, 0.f, sqnorm, 1);
+        VSOM_LAUNCH_CHECK("row_inv_norm_wide_kernel");
+    }
     hipLaunchKernelGGL(row_inv_norm_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, stream, X, ldx, rows, cols, 0.f, sqnorm,
                        vec, 1);
     VSOM_LAUNCH_CHECK("row_inv_norm_kernel");
