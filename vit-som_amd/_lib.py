@@ -116,9 +116,33 @@ _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 _cur_device = getattr(torch._C, "_cuda_getDevice", None)
 
 
+_forced_stream = None
+
+
+class on_stream:
+    """Launch the ops inside the block on the given torch stream WITHOUT making it torch's current
+    stream (``with torch.cuda.stream(s)`` costs ~10 us of host time per entry; this costs none).
+    Only for code that launches library kernels exclusively: torch's own ops still go to torch's
+    current stream."""
+
+    def __init__(self, torch_stream):
+        self.handle = torch_stream.cuda_stream
+
+    def __enter__(self):
+        global _forced_stream
+        self.prev, _forced_stream = _forced_stream, self.handle
+
+    def __exit__(self, *exc):
+        global _forced_stream
+        _forced_stream = self.prev
+
+
 def stream():
-    """Raw hipStream_t of torch's current stream on the current device (called once per launch:
-    the private fast accessors cost ~0.3 us, the public Stream object ~8 us)."""
+    """Raw hipStream_t the next launch goes to: the stream set by ``on_stream`` if any, else torch's
+    current stream on the current device (called once per launch: the private fast accessors cost
+    ~0.3 us, the public Stream object ~8 us)."""
+    if _forced_stream is not None:
+        return _forced_stream
     if _raw_stream is not None and _cur_device is not None:
         return _raw_stream(_cur_device())
     return torch.cuda.current_stream().cuda_stream

@@ -22,6 +22,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
+from ._lib import on_stream
 from .arena import ParamArena
 
 try:  # the reference subclasses pl.LightningModule; do the same when Lightning is importable
@@ -231,8 +232,10 @@ class ViTAutoencoder(nn.Module):
         # backward temporaries (shared by all layers; sized for the wider of encoder / decoder)
         W = max(E, DE)
         Hd = max([b.hidden for b in self.blocks] + [b.hidden for b in self.decoder_blocks])
-        a.g = [f(T * W) for _ in range(3)]
-        a.dh, a.dqkv, a.da = f(T * Hd), f(T * 3 * W), f(T * W)
+        # five rotating [T, dim] gradient buffers and two dh / dqkv sets: a buffer the side stream reads
+        # in one block is rewritten two blocks later at the earliest (see _side_join)
+        a.g = [f(T * W) for _ in range(5)]
+        a.dh2, a.dqkv2, a.da = [f(T * Hd), f(T * Hd)], [f(T * 3 * W), f(T * 3 * W)], f(T * W)
         a.delta = f(B * max(self.num_heads, self.decoder_num_heads) * N)
         a.dpred = f(T, pd)
         a.d_xe = f(T, E)
@@ -314,41 +317,56 @@ class ViTAutoencoder(nn.Module):
     # reads dW before the optimizer.  With a side stream set (ViTSOM does, on the GPU) they run
     # concurrently with the dX / LayerNorm / attention chain and fill its tail rounds and the
     # small-grid gaps.  Ordering: (1) a side GEMM waits for the main-stream kernel that produced
-    # its dY; (2) the dY buffers (gout / dh / g1 / dqkv) are only rewritten in the NEXT block, whose
-    # entry waits for the side work of this one (_side_join); (3) the owner joins the side stream
-    # before anything reads the gradients.  The saved activations the GEMMs read are not written
-    # during a backward pass.
+    # its dY; (2) the dY buffers (gout / g1 from a ring of five, dh / dqkv from two sets) are rewritten
+    # two blocks later at the earliest, and the entry of block j waits for the side work of block
+    # j+2 (_side_join) -- a wait that has normally long been satisfied, so the main stream does not
+    # stall on the ~15 us cross-stream signalling latency a wait on the PREVIOUS block costs;
+    # (3) the owner joins the side stream before anything reads the gradients.  The saved
+    # activations the GEMMs read are not written during a backward pass.
     _side = None
-    _side_done = None
+
+    def _event(self):
+        """Pooled events (re-recording one is safe once the waits on its previous record are enqueued)."""
+        pool = self.__dict__.setdefault("_ev_pool", [])
+        i = self.__dict__.get("_ev_next", 0)
+        if len(pool) < 64:
+            pool.append(torch.cuda.Event())
+        self.__dict__["_ev_next"] = (i + 1) % 64
+        return pool[i % len(pool)]
 
     def _dw(self, dy, x, gw, gb):
         side = self._side
         if side is None:
             return ops.linear_bwd_weight(dy, x, gw, gb)
-        ev = torch.cuda.Event()
-        ev.record()
-        with torch.cuda.stream(side):
-            side.wait_event(ev)
+        ev = self._event()
+        ev.record()                              # on the main (current) stream: dy is final here
+        side.wait_event(ev)
+        with on_stream(side):
             ops.linear_bwd_weight(dy, x, gw, gb)
 
-    def _side_join(self):
-        """Main stream waits for the side work of the previous block (before its dY buffers are reused)."""
-        if self._side is not None and self._side_done is not None:
-            torch.cuda.current_stream().wait_event(self._side_done)
-            self._side_done = None
+    def _side_join(self, keep: int = 1):
+        """Main stream waits for the side work of all but the `keep` most recent blocks."""
+        pend = self.__dict__.setdefault("_side_pending", [])
+        if self._side is None:
+            pend.clear()
+            return
+        while len(pend) > keep:
+            torch.cuda.current_stream().wait_event(pend.pop(0))
 
     def _side_mark(self):
         if self._side is not None:
-            self._side_done = self._side.record_event()
+            ev = self._event()
+            ev.record(self._side)
+            self.__dict__.setdefault("_side_pending", []).append(ev)
 
-    def _block_bwd(self, blk: Block, L: _Acts, x_in, gout, a: _Acts, G, prefix: str, bufs, WT=None):
+    def _block_bwd(self, blk: Block, L: _Acts, x_in, gout, a: _Acts, G, prefix: str, bufs, WT=None, parity: int = 0):
         """gout: gradient w.r.t. the block output [T,dim]; returns gradient w.r.t. x_in (in bufs)."""
         T, dim, hid = a.T, blk.dim, blk.hidden
-        self._side_join()
+        self._side_join(keep=1)            # side work of the block before the previous one must be done
         g1, g0 = bufs
-        dh = a.dh[:T * hid].view(T, hid)
+        dh = a.dh2[parity][:T * hid].view(T, hid)
         da = a.da[:T * dim].view(T, dim)
-        dqkv = a.dqkv[:T * 3 * dim].view(T, 3 * dim)
+        dqkv = a.dqkv2[parity][:T * 3 * dim].view(T, 3 * dim)
         self._dw(gout, L.hact, G(f"{prefix}.mlp.2.weight"), G(f"{prefix}.mlp.2.bias"))
         self._dx(WT, gout, blk.mlp["2"].weight, dh, gelu_grad=L.hpre)
         self._dw(dh, L.a2, G(f"{prefix}.mlp.0.weight"), G(f"{prefix}.mlp.0.bias"))
@@ -371,35 +389,37 @@ class ViTAutoencoder(nn.Module):
     def _decoder_bwd(self, a: _Acts, G, WT=None):
         """a.dpred holds dL/dpred; writes decoder grads and dL/d(xe) into a.d_xe (overwrite)."""
         DE = self.decoder_embed_dim
-        gA, gB, gC = self._views(a, DE)
+        ring = self._views(a, DE)
+        gA = ring[0]
         ops.linear_bwd_weight(a.dpred, a.dn, G("decoder_pred.weight"), G("decoder_pred.bias"))
         dn_grad = a.da[:a.T * DE].view(a.T, DE)
         self._dx(WT, a.dpred, self.decoder_pred.weight, dn_grad)
         x_last = a.dec[-1].x2 if a.dec else a.dec0
         ops.layernorm_bwd(dn_grad, x_last, a.mean_d, a.rstd_d, self.decoder_norm.weight, None, gA,
                           G("decoder_norm.weight"), G("decoder_norm.bias"))
-        gout, free = gA, [gB, gC]
-        for i in reversed(range(len(self.decoder_blocks))):
+        gout, pos = gA, 0
+        for j, i in enumerate(reversed(range(len(self.decoder_blocks)))):
             x_in = a.dec[i - 1].x2 if i > 0 else a.dec0
-            g0 = self._block_bwd(self.decoder_blocks[i], a.dec[i], x_in, gout, a, G, f"decoder_blocks.{i}", free, WT)
-            free = [b for b in (gA, gB, gC) if b is not g0]
-            gout = g0
+            bufs = [ring[(pos + 1) % 5], ring[(pos + 2) % 5]]
+            gout = self._block_bwd(self.decoder_blocks[i], a.dec[i], x_in, gout, a, G, f"decoder_blocks.{i}", bufs, WT, j & 1)
+            pos = (pos + 2) % 5
         ops.linear_bwd_weight(gout, a.xe, G("decoder_embed.weight"), G("decoder_embed.bias"))
         self._dx(WT, gout, self.decoder_embed.weight, a.d_xe)
 
     def _encoder_bwd(self, a: _Acts, G, WT=None):
         """a.d_xe holds dL/d(xe); writes every encoder gradient."""
-        self._side_join()                  # the decoder's last block may still be reading the shared buffers
+        self._side_join(keep=0)            # the decoder's blocks may still be reading the shared buffers
         E = self.embed_dim
-        gA, gB, gC = self._views(a, E)
+        ring = self._views(a, E)
+        gA = ring[0]
         x_last = a.enc[-1].x2 if a.enc else a.tok0
         ops.layernorm_bwd(a.d_xe, x_last, a.mean_e, a.rstd_e, self.norm.weight, None, gA, G("norm.weight"), G("norm.bias"))
-        gout, free = gA, [gB, gC]
-        for i in reversed(range(len(self.blocks))):
+        gout, pos = gA, 0
+        for j, i in enumerate(reversed(range(len(self.blocks)))):
             x_in = a.enc[i - 1].x2 if i > 0 else a.tok0
-            g0 = self._block_bwd(self.blocks[i], a.enc[i], x_in, gout, a, G, f"blocks.{i}", free, WT)
-            free = [b for b in (gA, gB, gC) if b is not g0]
-            gout = g0
+            bufs = [ring[(pos + 1) % 5], ring[(pos + 2) % 5]]
+            gout = self._block_bwd(self.blocks[i], a.enc[i], x_in, gout, a, G, f"blocks.{i}", bufs, WT, j & 1)
+            pos = (pos + 2) % 5
         p = self.patch_embed.patch_size[0]
         ops.patch_embed_bwd(gout, a.xp, G("patch_embed.proj.weight").view(E, -1), G("patch_embed.proj.bias"),
                             G("cls_token").view(E), a.B, self.in_chans, self.img_size, p, E)
@@ -1024,7 +1044,7 @@ class ViTSOM(_ArenaOwner, _Base):
         self.vit._encoder_bwd(a, Gv, self._WT)
         if self.vit._side is not None:
             torch.cuda.current_stream().wait_stream(self.vit._side)     # every gradient is final from here on
-            self.vit._side_done = None
+            self.vit.__dict__.setdefault("_side_pending", []).clear()
 
     # -- data-parallel exchange ----------------------------------------------------------------
     # -- reference API ---------------------------------------------------------------------------
