@@ -217,6 +217,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& g, const f32x16 (&acc
 #pragma unroll
                     for (int v = 0; v < 16; ++v) { rv[v] = *q; q += (((v & 3) == 3) ? 5 : 1) * g.ldr; }
                 }
+                float sv[16];
+                if constexpr (EPI == EPI_ROWAXPY) {
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) sv[v] = rs[(v & 3) + 8 * (v >> 2)];
+                }
                 const bool accum = MAY_ACC && g.accumulate;
                 if (accum) {
                     const float* q = d;
@@ -246,7 +251,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& g, const f32x16 (&acc
                     } else if constexpr (EPI == EPI_BIAS_RES) {
                         *d = a + bn + rv[v];
                     } else if constexpr (EPI == EPI_ROWAXPY) {
-                        float val = a + rs[(v & 3) + 8 * (v >> 2)] * rv[v];
+                        float val = a + sv[v] * rv[v];
                         if (accum) val += dv[v];
                         *d = val;
                     } else if constexpr (EPI == EPI_GELU_BWD) {

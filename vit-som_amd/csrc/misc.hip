@@ -195,11 +195,14 @@ __global__ __launch_bounds__(256) void transpose_many_kernel(const float* __rest
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const float* src = src_base + so;
     float* dst = dst_base + dof;
+    float v[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 4; ++i) {                    // all four loads in flight before the first LDS store
         const int r = r0 + ty + 8 * i, c = c0 + tx;
-        if (r < rows && c < cols) tile[ty + 8 * i][tx] = src[(long)r * cols + c];
+        v[i] = (r < rows && c < cols) ? src[(long)r * cols + c] : 0.f;
     }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) tile[ty + 8 * i][tx] = v[i];
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
