@@ -181,7 +181,11 @@ def main():
             "metric": "images/sec/node ViT-SOM 40x40 CIFAR-10 bs512 (training step: fwd+bwd+all-reduce+AdamW)",
             "value": round(world * B * args.steps / dt, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None,
+            # fp32 storage / accumulation / results; the Linear GEMMs reach the bf16 matrix cores through an exact
+            # 3-piece split of every fp32 operand (config.gemm_arithmetic), everything else is plain f32
+            "dtype": "f32" if ops.get_gemm_mode() == ops.GEMM_F32 else "f32 (Linear GEMMs: exact 3xbf16 operand split on bf16 MFMA)",
+            "data": "synthetic",
             "config": {"workload": "c3: vit_som CIFAR-10 shapes (3x32x32, patch 4, E=192, 3 heads, depth 12 + 2-layer "
                                    "decoder), 40x40 cosine SOM on the flattened patch tokens (L=12288), clustering loss "
                                    "L1(recon)+gamma*SOM, AdamW, random-init weights",
