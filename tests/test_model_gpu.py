@@ -278,6 +278,48 @@ def test_c5_shapes_tiny_imagenet_40x40():
     assert m.som_layer.latent_dim == 49152 and m.vit.patch_embed.num_patches == 256
 
 
+def test_full_size_c3_step_properties():
+    """BASELINE c3 at its FULL size (CIFAR-10 shapes, 12 + 2 layers, 40x40 SOM, batch 512: the bench
+    workload), where the CPU oracle would take minutes: size-independent properties instead.
+      * BMU policy: bmu == argmin (first minimum) of the distances the step itself produced, bit for bit;
+      * distances against an fp64 evaluation (on the device, plain torch) of 1 - xhat . what from the SOM input;
+      * determinism: a second, identically seeded model gives a bit-identical loss and gradient arena;
+      * linearity of the backward pass in the loss seed: backward(2 * loss) == 2 * backward(loss), bit for bit
+        (powers of two commute with fp32 rounding);
+      * the weighted SOM loss equals mean(h * dist) recomputed in fp64 from the kernel's own (bmu, T)."""
+    import vit_som_amd
+    import bench
+    cfg = bench.c3_config(512)
+    arenas, losses = [], []
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(512, 3, 32, 32, generator=g).to(DEV)
+    y = torch.zeros(512, dtype=torch.int64, device=DEV)
+    for rep in range(2):
+        torch.manual_seed(0)
+        m = vit_som_amd.ViTSOM(copy.deepcopy(cfg), device=DEV)
+        m.set_schedule(50000, 9700)
+        m._it = 1000
+        loss = m.training_step((x, y), 0)
+        (loss * (2.0 if rep else 1.0)).backward()
+        arenas.append(m.arena.grads.clone())
+        losses.append(float(loss.detach()))
+    assert losses[0] == losses[1]
+    assert torch.equal(arenas[1], 2.0 * arenas[0])                     # deterministic AND linear in the seed
+    a, s = m._ctx[1], m._ctx[2]
+    assert torch.equal(s.bmu, s.dist.argmin(dim=1))
+    X = m._som_input(a).double()
+    W = m.som_layer.prototypes.detach().double()
+    ref = 1.0 - torch.nn.functional.normalize(X, dim=1) @ torch.nn.functional.normalize(W, dim=1).T
+    assert float((s.dist.double() - ref).abs().max()) < 2e-6
+    gap = ref.topk(2, dim=1, largest=False).values
+    sure = (gap[:, 1] - gap[:, 0]) > 4e-6                             # rows whose fp64 winner is unambiguous in fp32
+    assert int(sure.sum()) > 400 and torch.equal(s.bmu[sure], ref.argmin(dim=1)[sure])
+    T = float(m.som_layer.current_temperature)
+    pos = m.som_layer.grid_positions.double()
+    h = torch.exp(-(pos[None, :, :] - pos[s.bmu][:, None, :]).pow(2).sum(-1) / (2 * T * T))
+    assert abs(float(m._last["som"]) - float((h * s.dist.double()).mean())) < 1e-7
+
+
 @pytest.mark.parametrize("B", [1, 3, 7])
 def test_small_and_odd_batches(B):
     from oracle import vitsom_oracle as O
