@@ -101,6 +101,34 @@ def test_shipped_config_shapes_against_oracle():
         assert rel_err(m._grad_views[n].cpu(), gref) < 1e-4 or float((m._grad_views[n].cpu() - gref).abs().max()) < 1e-10, n
 
 
+def test_flowers17_config_shapes_against_oracle():
+    """configs/desom/desom_flowers17.yaml: 3x224x224 inputs (150 528 features, a 75 M-parameter first layer),
+    17 classes (CE + gamma (SOM + recon)); batch reduced to 16 so the CPU oracle stays in seconds."""
+    import vit_som_amd
+    from oracle import desom_oracle as D
+    from oracle.gen_golden_desom import make_config
+    cfg = make_config(3, 224, [500, 500, 2000, 10], (8, 8), 17, 16)
+    torch.manual_seed(1)
+    m = vit_som_amd.DESOM(copy.deepcopy(cfg), device="cuda")
+    m.set_schedule(1360)
+    m._it = 7
+    g = torch.Generator().manual_seed(4)
+    x = torch.rand(16, 3, 224, 224, generator=g)
+    y = torch.randint(0, 17, (16,), generator=g)
+    P = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    names = dict(m.named_parameters())
+    Q = {k: (v.requires_grad_(True) if k in names else v) for k, v in P.items()}
+    total_ref, parts = D.training_loss(Q, cfg, x, y, D.temperature(cfg, 7, 1360))
+    total_ref.backward()
+    loss = m.train_step_fused(x.cuda(), y.cuda())
+    assert abs(float(loss) - float(total_ref.detach())) < 2e-5
+    assert torch.equal(m._ctx[2].bmu.cpu(), parts["bmu"])
+    for n in names:
+        gref = Q[n].grad
+        got = m._grad_views[n].cpu()
+        assert rel_err(got, gref) < 1e-4 or float((got - gref).abs().max()) < 1e-10, n
+
+
 def test_rejects_what_has_no_kernel():
     import vit_som_amd
     _, cfg = load_golden("ref_desom_tiny")
