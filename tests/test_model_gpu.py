@@ -320,6 +320,42 @@ def test_full_size_c3_step_properties():
     assert abs(float(m._last["som"]) - float((h * s.dist.double()).mean())) < 1e-7
 
 
+@pytest.mark.parametrize("name,img,classes,map_size,B", [("c4", 32, 100, (4, 4), 128), ("c5", 64, 200, (40, 40), 256)])
+def test_full_size_c4_c5_step_properties(name, img, classes, map_size, B):
+    """BASELINE c4 (CIFAR-100 shapes, 4x4 SOM, 1024 global = 128 per GPU) and c5 (Tiny-ImageNet 64x64 -> 257
+    tokens, L = 49152, 40x40 SOM, 256 per GPU) at full depth and per-GPU batch, classification mode:
+    determinism, the BMU policy, distances against fp64, logits against an fp64 head, zero decoder gradients."""
+    import vit_som_amd
+    from oracle.gen_golden import make_config
+    cfg = make_config(3, img, 4, 192, 12, 3, 96, 2, map_size, classes, B, gamma=0.01, Tmax=4.0, Tmin=0.1)
+    g = torch.Generator().manual_seed(13)
+    x = torch.randn(B, 3, img, img, generator=g).to(DEV)
+    y = torch.randint(0, classes, (B,), generator=g).to(DEV)
+    arenas, losses = [], []
+    for rep in range(2):
+        torch.manual_seed(0)
+        m = vit_som_amd.ViTSOM(copy.deepcopy(cfg), device=DEV)
+        m.set_schedule(100000, 5000)
+        m._it = 500
+        losses.append(float(m.train_step_fused(x, y)))
+        arenas.append(m.arena.grads.clone())
+        if rep == 0:
+            del m
+    assert losses[0] == losses[1] and torch.equal(arenas[0], arenas[1])
+    a, s = m._ctx[1], m._ctx[2]
+    assert torch.equal(s.bmu, s.dist.argmin(dim=1))
+    X = m._som_input(a).double()
+    W = m.som_layer.prototypes.detach().double()
+    ref = 1.0 - torch.nn.functional.normalize(X, dim=1) @ torch.nn.functional.normalize(W, dim=1).T
+    assert float((s.dist.double() - ref).abs().max()) < 2e-6
+    cls_tok = m._cls_view(a.xe, a).double()
+    logits_ref = cls_tok @ m.cls_head.weight.detach().double().T + m.cls_head.bias.detach().double()
+    assert float((a.logits.double() - logits_ref).abs().max()) < 1e-5
+    for n in m._decoder_param_names():
+        assert float(m._grad_views[n].abs().max()) == 0.0
+    assert all(bool(torch.isfinite(v).all()) for v in m._grad_views.values())
+
+
 @pytest.mark.parametrize("B", [1, 3, 7])
 def test_small_and_odd_batches(B):
     from oracle import vitsom_oracle as O
