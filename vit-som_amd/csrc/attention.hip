@@ -22,6 +22,7 @@
 // additional wave with VALU only (lane per key for the dots, lane per channel for the sums).
 #include "common.h"
 
+#include <stdlib.h>
 namespace vsom {
 
 constexpr int MAXCH = 5;   // EXTRA mode: the VALU wave walks the rows in chunks of 64 -> N <= 320
@@ -630,6 +631,185 @@ __global__ __launch_bounds__(576) void attn_bwd_dkv_kernel(const float* __restri
     }
 }
 
+// ------------------------------------------------------------------ backward, fused (short sequences)
+// dQ and dK/dV in ONE launch when all four slices (K, V, Q, dO) of an (image, head) fit in LDS next to
+// each other (N = 65, hd = 64: 72 KB): the slices are staged once, D = rowsum(dO * O) goes from the dQ
+// phase to the dK/dV phase through LDS, and the second kernel's launch, staging and prologue
+// disappear.  Phase 1 is attn_bwd_dq_kernel's body (waves own query tiles), phase 2
+// attn_bwd_dkv_kernel's (waves own key tiles); the token-0 vectors of the EXTRA path are row 0 of the
+// staged slices.
+template <int HDP, bool EXTRA>
+__global__ __launch_bounds__(576) void attn_bwd_fused_kernel(const float* __restrict__ qkv, const float* __restrict__ out,
+                                                             const float* __restrict__ dout, const float* __restrict__ lse,
+                                                             float* __restrict__ dqkv, float* __restrict__ delta, int N,
+                                                             int H, int hd, float scale) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int NDT = ACfg<HDP>::NDT;
+    constexpr int NMM = ACfg<HDP>::NMM;
+    constexpr int S = ACfg<HDP>::S;
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const int E = H * hd, E3 = 3 * E;
+    const int ntile = EXTRA ? (N - 1) >> 4 : (N + 15) >> 4;
+    const int nrows = EXTRA ? N : ntile << 4;
+    const int nrp = (nrows + 3) & ~3;
+    float* Ks = smem;
+    float* Vs = Ks + nrows * S;
+    float* Qs = Vs + nrows * S;
+    float* Ds = Qs + nrows * S;
+    float* Ls = Ds + nrows * S;
+    float* Es = Ls + nrp;
+    float* W1 = Es + nrp;
+    float* W2 = W1 + nrp;
+    const float* base = qkv + (long)b * N * E3 + h * hd;
+    const long obase = (long)b * N * E + h * hd;
+    const long srow0 = ((long)b * H + h) * N;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    const int tile_waves = nwaves - (EXTRA ? 1 : 0);
+    const bool extra_wave = EXTRA && wave == tile_waves;
+    const int r = lane & 15, qp = lane >> 4;
+    float qf[NMM], dof[NMM], of[NMM];
+    if (!extra_wave) {
+        const int q0 = tok<EXTRA>(wave, r);
+        load_frag<HDP>(qf, base + (long)q0 * E3, qp, q0 < N, hd);
+        load_frag<HDP>(dof, dout + obase + (long)q0 * E, qp, q0 < N, hd);
+        load_frag<HDP>(of, out + obase + (long)q0 * E, qp, q0 < N, hd);
+    }
+    float l_r = 0.f;
+    if ((int)threadIdx.x < N) l_r = lse[srow0 + threadIdx.x];
+    stage_rows_pair<HDP>(Ks, base + E, E3, Vs, base + 2 * E, E3, N, nrows, hd);
+    stage_rows_pair<HDP>(Qs, base, E3, Ds, dout + obase, E, N, nrows, hd);
+    for (int i = threadIdx.x; i < nrp; i += blockDim.x) {
+        Ls[i] = (i == (int)threadIdx.x) ? l_r : ((i < N) ? lse[srow0 + i] : 0.f);
+        Es[i] = 0.f;
+    }
+    __syncthreads();
+
+    // ---- phase 1: dQ and D
+    if (extra_wave) {                                                  // token 0 as a query: VALU only
+        const float* q0v = Qs;                                         // row 0 of the staged slices
+        const float* do0 = Ds;
+        float d0 = (lane < hd) ? do0[lane] * out[obase + lane] : 0.f;
+        const float D0 = wave_sum(d0);
+        if (lane == 0) { delta[srow0] = D0; Es[0] = D0; }
+        const float l0 = Ls[0];
+        float sc[MAXCH], dp[MAXCH];
+        rows_dot<HDP>(sc, q0v, Ks, N, lane);
+        rows_dot<HDP>(dp, do0, Vs, N, lane);
+#pragma unroll
+        for (int c = 0; c < MAXCH; ++c) {
+            if (64 * c + lane < N) {
+                const float p = __expf(sc[c] * scale - l0);
+                W1[64 * c + lane] = p * (dp[c] - D0) * scale;
+            }
+        }
+        lds_fence_wave();
+        if (lane < HDP) {
+            const float gq = rows_wsum<HDP>(W1, Ks, N, lane);
+            if (lane < hd) dqkv[(long)b * N * E3 + h * hd + lane] = gq;
+        }
+    } else {
+        for (int qt = wave; qt < ntile; qt += tile_waves) {
+            const int query = tok<EXTRA>(qt, r);
+            const bool qok = query < N;
+            if (qt != wave) {
+                load_frag<HDP>(qf, base + (long)query * E3, qp, qok, hd);
+                load_frag<HDP>(dof, dout + obase + (long)query * E, qp, qok, hd);
+                load_frag<HDP>(of, out + obase + (long)query * E, qp, qok, hd);
+            }
+            float D = 0.f;
+#pragma unroll
+            for (int mm = 0; mm < NMM; ++mm) D = fmaf(dof[mm], of[mm], D);
+            D = group_sum(D);
+            if (qp == 0 && qok) { delta[srow0 + query] = D; Es[query] = D; }
+            const float lq = qok ? Ls[query] : 0.f;
+            f32x4 dq[NDT];
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (EXTRA) {                                               // token 0 as a key
+                const float s0 = frag_dot_row<HDP>(qf, Ks, qp) * scale;
+                const float dp0 = frag_dot_row<HDP>(dof, Vs, qp);
+                const float p0 = __expf(s0 - lq);
+                axpy_row<HDP>(dq, p0 * (dp0 - D) * scale, Ks, qp);
+            }
+            for (int t = 0; t < ntile; ++t) {
+                f32x4 sc, dp;
+                score_tile2<HDP>(Ks, tok<EXTRA>(t, 0), qf, Vs, tok<EXTRA>(t, 0), dof, r, qp, sc, dp);
+                f32x4 ds;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int key = tok<EXTRA>(t, 4 * qp + e);
+                    const float p = (EXTRA || (key < N && qok)) ? __expf(sc[e] * scale - lq) : 0.f;
+                    ds[e] = p * (dp[e] - D) * scale;
+                }
+                accum_tile<HDP>(dq, Ks, tok<EXTRA>(t, 0), r, qp, ds);
+            }
+            store_rows<HDP>(dq, dqkv + ((long)b * N + query) * E3 + h * hd, qp, qok, hd);
+        }
+    }
+    __syncthreads();                                                   // Es (D of every row) complete; W1 free again
+
+    // ---- phase 2: dK, dV
+    if (extra_wave) {                                                  // token 0 as a key: VALU only
+        const float* k0v = Ks;
+        const float* v0v = Vs;
+        float sc[MAXCH], dp[MAXCH];
+        rows_dot<HDP>(sc, k0v, Qs, N, lane);                           // s_j = q_j . k_0
+        rows_dot<HDP>(dp, v0v, Ds, N, lane);                           // dp_j = dO_j . v_0
+#pragma unroll
+        for (int c = 0; c < MAXCH; ++c) {
+            const int j = 64 * c + lane;
+            if (j < N) {
+                const float p = __expf(sc[c] * scale - Ls[j]);
+                W1[j] = p;
+                W2[j] = p * (dp[c] - Es[j]) * scale;
+            }
+        }
+        lds_fence_wave();
+        if (lane < HDP) {
+            const float gv = rows_wsum<HDP>(W1, Ds, N, lane);
+            const float gk = rows_wsum<HDP>(W2, Qs, N, lane);
+            if (lane < hd) {
+                float* drow = dqkv + (long)b * N * E3 + h * hd;
+                drow[E + lane] = gk;
+                drow[2 * E + lane] = gv;
+            }
+        }
+        return;
+    }
+    for (int kt = wave; kt < ntile; kt += tile_waves) {
+        const int key = tok<EXTRA>(kt, r);
+        const bool kok = key < N;
+        float kf[NMM], vf[NMM];
+        load_frag<HDP>(kf, Ks + (long)(kok ? key : 0) * S, qp, kok, HDP);      // own rows from the staged slices
+        load_frag<HDP>(vf, Vs + (long)(kok ? key : 0) * S, qp, kok, HDP);
+        f32x4 dk[NDT], dv[NDT];
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) { dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        if (EXTRA) {                                                   // token 0 as a query
+            const float s0 = frag_dot_row<HDP>(kf, Qs, qp) * scale;
+            const float dp0 = frag_dot_row<HDP>(vf, Ds, qp);
+            const float p0 = __expf(s0 - Ls[0]);
+            axpy_row<HDP>(dv, p0, Ds, qp);
+            axpy_row<HDP>(dk, p0 * (dp0 - Es[0]) * scale, Qs, qp);
+        }
+        for (int t = 0; t < ntile; ++t) {
+            f32x4 sc, dp;                                              // rows: queries of tile t, col: own key
+            score_tile2<HDP>(Qs, tok<EXTRA>(t, 0), kf, Ds, tok<EXTRA>(t, 0), vf, r, qp, sc, dp);
+            f32x4 p, ds;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int query = tok<EXTRA>(t, 4 * qp + e);
+                p[e] = (EXTRA || (query < N && kok)) ? __expf(sc[e] * scale - Ls[query]) : 0.f;
+                ds[e] = p[e] * (dp[e] - Es[query]) * scale;
+            }
+            accum_tile2<HDP>(dv, Ds, p, dk, Qs, ds, tok<EXTRA>(t, 0), r, qp);
+        }
+        float* drow = dqkv + ((long)b * N + key) * E3 + h * hd;
+        store_rows<HDP>(dk, drow + E, qp, kok, hd);
+        store_rows<HDP>(dv, drow + 2 * E, qp, kok, hd);
+    }
+}
+
 // ------------------------------------------------------------------ host side
 // (A persistent variant -- workgroups looping over (image, head) items with register prefetch of
 // the next item's rows -- was measured and rejected: the extra registers drop residency from 3-4 to
@@ -653,6 +833,12 @@ static size_t attn_lds_bytes(int N, int hdp, bool with_stats) {
     return ((size_t)2 * nrows * (hdp + 4) + (with_stats ? 2 * nrp : 0) + 2 * hdp + 2 * nrp) * sizeof(float);
 }
 
+static size_t attn_fused_lds_bytes(int N, int hdp) {
+    const int nrows = use_extra(N) ? N : cdiv(N, 16) * 16;
+    const int nrp = (nrows + 3) & ~3;
+    return ((size_t)4 * nrows * (hdp + 4) + 4 * nrp) * sizeof(float);
+}
+
 template <int HDP, bool EXTRA>
 static int launch_fwd_t(const float* qkv, float* out, float* lse, int B, int N, int H, int hd, hipStream_t st) {
     const size_t lds = attn_lds_bytes(N, HDP, false);
@@ -665,6 +851,13 @@ static int launch_bwd_t(const float* qkv, const float* out, const float* dout, c
                         float* delta, int B, int N, int H, int hd, hipStream_t st) {
     const float scale = 1.0f / sqrtf((float)hd);
     const dim3 block(64 * (attn_waves(N) + (EXTRA ? 1 : 0)));
+    // all four slices in LDS and still two workgroups per CU -> one fused launch (vector path only)
+    const size_t fused_lds = attn_fused_lds_bytes(N, HDP);
+    if (ACfg<HDP>::VEC && fused_lds <= 80 * 1024 && !(getenv("VSOM_ATTN_FUSED") && !atoi(getenv("VSOM_ATTN_FUSED")))) {
+        hipLaunchKernelGGL((attn_bwd_fused_kernel<HDP, EXTRA>), dim3(B * H), block, fused_lds, st, qkv, out, dout, lse, dqkv,
+                           delta, N, H, hd, scale);
+        VSOM_LAUNCH_CHECK("attn_bwd_fused_kernel");
+    }
     hipLaunchKernelGGL((attn_bwd_dq_kernel<HDP, EXTRA>), dim3(B * H), block, attn_lds_bytes(N, HDP, false), st, qkv, out, dout,
                        lse, dqkv, delta, N, H, hd, scale);
     int rc = hip_status(hipGetLastError(), "attn_bwd_dq_kernel");
