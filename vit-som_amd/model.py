@@ -260,8 +260,46 @@ class ViTAutoencoder(nn.Module):
         ops.patch_embed_fwd(x, self.patch_embed.proj.weight.view(E, -1), self.patch_embed.proj.bias, self.pos_embed[0],
                             self.cls_token.view(E), a.tok0, a.xp, p)
         cur = a.tok0
-        for blk, L in zip(self.blocks, a.enc):
-            cur = self._block_fwd(blk, L, cur, a.B, a.N)
+        side = None
+        if cur.is_cuda and a.B % 2 == 0 and a.B >= 64 and os.environ.get("VSOM_FWD_SPLIT", "1") != "0":
+            side = self.__dict__.get("_fwd_side")
+            if side is None or side.device != cur.device:
+                side = self.__dict__["_fwd_side"] = torch.cuda.Stream(device=cur.device)
+        if side is not None:
+            # The forward is one dependent chain per image: the two halves of the batch run as two
+            # chains on two streams (row-sliced views of the same buffers, so the results are the same
+            # bits and the backward sees one batch); staggered against each other, one chain's
+            # latency-bound kernels (attention, LayerNorm) run under the other's GEMMs.
+            Bh, Th = a.B // 2, a.T // 2
+            halves = a.__dict__.get("_enc_halves")
+            if halves is None:
+                def cut(L, h):
+                    Lh = _Acts()
+                    for k, v in L.__dict__.items():
+                        Lh.__dict__[k] = v[h * Bh:(h + 1) * Bh] if k == "lse" else v[h * Th:(h + 1) * Th]
+                    return Lh
+                halves = a.__dict__["_enc_halves"] = [[cut(L, h) for L in a.enc] for h in (0, 1)]
+            ev = self._event()
+            ev.record()
+            side.wait_event(ev)
+            outs = []
+            for h in (0, 1):
+                c = a.tok0[h * Th:(h + 1) * Th]
+                if h == 1:
+                    with on_stream(side):
+                        for blk, L in zip(self.blocks, halves[1]):
+                            c = self._block_fwd(blk, L, c, Bh, a.N)
+                else:
+                    for blk, L in zip(self.blocks, halves[0]):
+                        c = self._block_fwd(blk, L, c, Bh, a.N)
+                outs.append(c)
+            ev2 = self._event()
+            ev2.record(side)
+            torch.cuda.current_stream().wait_event(ev2)
+            cur = a.enc[-1].x2
+        else:
+            for blk, L in zip(self.blocks, a.enc):
+                cur = self._block_fwd(blk, L, cur, a.B, a.N)
         ops.layernorm_fwd(cur, self.norm.weight, self.norm.bias, a.xe, a.mean_e, a.rstd_e, self.eps)
         return a.xe
 
