@@ -216,8 +216,70 @@ def test_stream_level_concurrency_is_bitwise_identical(monkeypatch):
             opt.step()
         assert (m.vit._side is not None) == (side == "1")
         assert (m.vit.__dict__.get("_fwd_side") is not None) == (split == "1")
+        assert split == "0" or m.vit._fwd_side is m._side_stream          # the second chain borrows the backward's side stream
         finals.append(m.arena.params.clone())
     assert all(torch.equal(finals[0], f) for f in finals[1:])
+
+
+def test_use_reduced_cls_token_som():
+    """use_reduced=True: SOM on the CLS token (L = E), vit_som.py:70-71."""
+    from oracle import vitsom_oracle as O
+    z, cfg = load_golden("ref_cls_tiny")
+    cfg = copy.deepcopy(cfg)
+    cfg["hyperparameters"]["som"]["use_reduced"] = True
+    d = O.Dims(cfg)
+    P = O.init_params(cfg, seed=7)
+    x, y = O.synthetic_batch(d, 5, seed=3)
+    total, parts, G = O.loss_and_grads(P, x, y, d, 6, 50, 20)
+    m = build(cfg, P)
+    m._it = 6
+    m.set_schedule(50, 20)
+    loss = m.training_step((x.to(DEV), y.to(DEV)), 0)
+    loss.backward()
+    assert abs(float(loss) - float(total)) < 2e-5
+    for n, p in m.named_parameters():
+        if p.requires_grad:
+            assert rel_err(p.grad.cpu(), G[n]) < 1e-4 or float((p.grad.cpu() - G[n]).abs().max()) < 1e-9, n
+
+
+def _shape_case(cfg, B, seed, it=30, n_train=100000, est=400, grad_tol=2e-4):
+    from oracle import vitsom_oracle as O
+    d = O.Dims(cfg)
+    P = O.init_params(cfg, seed=seed)
+    x, y = O.synthetic_batch(d, B, seed=seed + 1)
+    total, parts, G = O.loss_and_grads(P, x, y, d, it, n_train, est)
+    m = build(cfg, P)
+    m._it = it
+    m.set_schedule(n_train, est)
+    loss = m.training_step((x.to(DEV), y.to(DEV)), 0)
+    s = m._ctx[2]
+    assert abs(float(loss) - float(total)) < 1e-4
+    assert torch.allclose(s.dist.cpu(), parts["dist"], atol=2e-5)
+    assert bmu_ok(s.bmu.cpu(), parts["dist"].double())
+    if m.classification:
+        assert torch.allclose(m._ctx[1].logits.cpu(), parts["logits"], atol=1e-4)
+    loss.backward()
+    if torch.equal(s.bmu.cpu(), parts["bmu"]):
+        for n, p in m.named_parameters():
+            if p.requires_grad:
+                e = rel_err(p.grad.cpu(), G[n])
+                assert e < grad_tol or float((p.grad.cpu() - G[n]).abs().max()) < 1e-9, (n, e)
+    return m
+
+
+def test_c4_shapes_cifar100_classification_head():
+    """BASELINE config c4: vit_som-cls, CIFAR-100 (100 classes), 4x4 SOM (K=16, HBM-bound BMU shape)."""
+    from oracle.gen_golden import make_config
+    cfg = make_config(3, 32, 4, 192, 2, 3, 96, 2, (4, 4), 100, 24, gamma=0.01, Tmax=4.0, Tmin=0.1)
+    _shape_case(cfg, 24, seed=21)
+
+
+def test_c5_shapes_tiny_imagenet_40x40():
+    """BASELINE config c5: Tiny-ImageNet 64x64 -> N=257 tokens, L=49152, 40x40 SOM (the largest shapes)."""
+    from oracle.gen_golden import make_config
+    cfg = make_config(3, 64, 4, 192, 1, 3, 96, 1, (40, 40), 0, 4, gamma=0.01, Tmax=4.0, Tmin=0.1)
+    m = _shape_case(cfg, 4, seed=31, grad_tol=3e-4)
+    assert m.som_layer.latent_dim == 49152 and m.vit.patch_embed.num_patches == 256
 
 
 def test_full_size_c3_step_properties():

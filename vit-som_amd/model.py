@@ -262,37 +262,39 @@ class ViTAutoencoder(nn.Module):
         cur = a.tok0
         side = None
         if cur.is_cuda and a.B % 2 == 0 and a.B >= 64 and os.environ.get("VSOM_FWD_SPLIT", "1") != "0":
-            side = self.__dict__.get("_fwd_side")
+            # the owner (ViTSOM) lends the stream its backward uses for the weight gradients -- idle during
+            # the forward; a stream of its own would compete for the few hardware queues of the process
+            # (measured: erratic, sometimes slower than one chain)
+            side = self.__dict__.get("_lent_stream")
             if side is None or side.device != cur.device:
-                side = self.__dict__["_fwd_side"] = torch.cuda.Stream(device=cur.device)
+                side = self.__dict__.get("_fwd_side")
+                if side is None or side.device != cur.device:
+                    side = torch.cuda.Stream(device=cur.device)
+        self.__dict__["_fwd_side"] = side
         if side is not None:
-            # The forward is one dependent chain per image: the two halves of the batch run as two
-            # chains on two streams (row-sliced views of the same buffers, so the results are the same
-            # bits and the backward sees one batch); staggered against each other, one chain's
-            # latency-bound kernels (attention, LayerNorm) run under the other's GEMMs.
+            # The forward is one dependent chain per image: the two halves of the batch run as two chains
+            # on two streams (row-sliced views of the same buffers, so the results are the same bits and
+            # the backward sees one batch); staggered against each other, one chain's latency-bound
+            # kernels (attention, LayerNorm) run under the other's GEMMs.
             Bh, Th = a.B // 2, a.T // 2
-            halves = a.__dict__.get("_enc_halves")
-            if halves is None:
+            cuts = a.__dict__.get("_enc_halves")
+            if cuts is None:
                 def cut(L, h):
                     Lh = _Acts()
                     for k, v in L.__dict__.items():
                         Lh.__dict__[k] = v[h * Bh:(h + 1) * Bh] if k == "lse" else v[h * Th:(h + 1) * Th]
                     return Lh
-                halves = a.__dict__["_enc_halves"] = [[cut(L, h) for L in a.enc] for h in (0, 1)]
+                cuts = a.__dict__["_enc_halves"] = [[cut(L, h) for L in a.enc] for h in (0, 1)]
             ev = self._event()
             ev.record()
             side.wait_event(ev)
-            outs = []
-            for h in (0, 1):
-                c = a.tok0[h * Th:(h + 1) * Th]
-                if h == 1:
-                    with on_stream(side):
-                        for blk, L in zip(self.blocks, halves[1]):
-                            c = self._block_fwd(blk, L, c, Bh, a.N)
-                else:
-                    for blk, L in zip(self.blocks, halves[0]):
-                        c = self._block_fwd(blk, L, c, Bh, a.N)
-                outs.append(c)
+            c = a.tok0[:Th]
+            for blk, L in zip(self.blocks, cuts[0]):
+                c = self._block_fwd(blk, L, c, Bh, a.N)
+            c = a.tok0[Th:]
+            with on_stream(side):
+                for blk, L in zip(self.blocks, cuts[1]):
+                    c = self._block_fwd(blk, L, c, Bh, a.N)
             ev2 = self._event()
             ev2.record(side)
             torch.cuda.current_stream().wait_event(ev2)
@@ -952,6 +954,7 @@ class ViTSOM(_ArenaOwner, _Base):
         if not x.is_cuda:
             raise ValueError("ViTSOM: input must live on the MI355X (there is no CPU path)")
         a = self.vit._buffers_for(x.shape[0], x.device)
+        self._ensure_streams(x.device)
         self.vit._encode(x, a)
         if need_decoder:
             self.vit._decode(a)
@@ -1018,6 +1021,13 @@ class ViTSOM(_ArenaOwner, _Base):
         self._last = {"main": main, "som": som, "total": total, "gamma_t": gamma_t, "T": T}
         return total
 
+    def _ensure_streams(self, device):
+        """The two extra HIP streams of the step (kept to two: a process has few hardware queues)."""
+        if getattr(self, "_side_stream", None) is None or self._side_stream.device != device:
+            self._side_stream = torch.cuda.Stream(device=device)      # weight-gradient GEMMs; second forward chain
+            self._som_stream = torch.cuda.Stream(device=device)       # SOM backward + early all-reduce
+        self.vit.__dict__["_lent_stream"] = self._side_stream
+
     @torch.no_grad()
     def _backward(self):
         """All backward kernels; overwrites the whole gradient arena (no accumulation)."""
@@ -1025,9 +1035,7 @@ class ViTSOM(_ArenaOwner, _Base):
         self._grads_reduced = False
         self._early = None
         if x.is_cuda and os.environ.get("VSOM_SIDE_STREAM", "1") != "0":
-            if getattr(self, "_side_stream", None) is None or self._side_stream.device != x.device:
-                self._side_stream = torch.cuda.Stream(device=x.device)      # weight-gradient GEMMs
-                self._som_stream = torch.cuda.Stream(device=x.device)       # SOM backward + early all-reduce
+            self._ensure_streams(x.device)
             self.vit._side = self._side_stream
         else:
             self.vit._side = None
