@@ -288,17 +288,25 @@ class ViTAutoencoder(nn.Module):
             ev = self._event()
             ev.record()
             side.wait_event(ev)
+            # Only the first half of the blocks: the denser the forward runs, the lower the clock the power
+            # management leaves for the kernels right after it -- the f32-MFMA BMU pass took 168 / 175 / 185 /
+            # 189 us with 0 / 6 / 10 / 12 of 12 blocks split (step 12.10 / 11.93 / 11.85 / 11.81 ms); half keeps
+            # most of the gain and most of the BMU pass's speed.
+            nsplit = int(os.environ.get("VSOM_FWD_SPLIT_BLOCKS", str(len(self.blocks) // 2)))
+            nsplit = max(0, min(nsplit, len(self.blocks)))
             c = a.tok0[:Th]
-            for blk, L in zip(self.blocks, cuts[0]):
+            for blk, L in zip(self.blocks[:nsplit], cuts[0][:nsplit]):
                 c = self._block_fwd(blk, L, c, Bh, a.N)
             c = a.tok0[Th:]
             with on_stream(side):
-                for blk, L in zip(self.blocks, cuts[1]):
+                for blk, L in zip(self.blocks[:nsplit], cuts[1][:nsplit]):
                     c = self._block_fwd(blk, L, c, Bh, a.N)
             ev2 = self._event()
             ev2.record(side)
             torch.cuda.current_stream().wait_event(ev2)
-            cur = a.enc[-1].x2
+            cur = a.enc[nsplit - 1].x2 if nsplit > 0 else a.tok0
+            for blk, L in zip(self.blocks[nsplit:], a.enc[nsplit:]):
+                cur = self._block_fwd(blk, L, cur, a.B, a.N)
         else:
             for blk, L in zip(self.blocks, a.enc):
                 cur = self._block_fwd(blk, L, cur, a.B, a.N)
