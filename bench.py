@@ -201,7 +201,7 @@ def main():
                          # HBM-side bytes per launch from rocprofv3 PMC passes of this same command (2 x FETCH_SIZE +
                          # WRITE_SIZE, profiles/r01_bench_n1_pmc_hbm_traffic.txt: 143-164 MB read depending on what the
                          # preceding kernels left in the L2 / MALL, 22.9 MB written); only valid for the default workload
-                         "traffic": (164.0e6 + 22.9e6) if (B == 512 and world == 1) else None,
+                         "traffic": (164.5e6 + 22.9e6) if (B == 512 and world == 1) else None,
                          "avg_launch_ms": round(bmu_ms, 4), "launches_timed": bmu_calls,
                          "algorithmic_flops": bmu_flops, "algorithmic_bytes": bmu_bytes,
                          "hbm_view": {"achieved_GBps": round(bmu_bytes / t_s / 1e9, 1), "peak_GBps": HBM_PEAK_GBS,
