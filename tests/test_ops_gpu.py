@@ -173,7 +173,8 @@ def test_gemm_mode_switch(ops):
 
 
 @pytest.mark.parametrize("M,N,K", [(1000, 576, 192), (4160, 192, 768), (70, 10, 24), (33, 4, 16), (650, 48, 96),
-                                    (2080, 768, 192)])
+                                    (2080, 768, 192), (650, 288, 96), (1301, 96, 384), (31, 192, 64), (33280, 192, 192),
+                                    (33280, 576, 192)])
 def test_linear_bwd_weight(ops, gemm_mode, M, N, K):
     dy, x = rnd(M, N, seed=1), rnd(M, K, seed=2)
     dW_ref, db_ref = dy.double().T @ x.double(), dy.double().sum(0)

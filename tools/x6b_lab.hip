@@ -1,0 +1,431 @@
+// Lab: split-bf16 NT GEMM with large tiles and pre-split ("plane") operands.
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -o tools/x6b_lab tools/x6b_lab.hip
+// usage: x6b_lab M N K
+//
+// Operand modes (per operand):
+//   0  fp32 [rows][K] in HBM, split into three bf16 planes inside the kernel (register staged)
+//   1  pre-split planes in HBM, layout i32 = [row][K/32][3 planes][32] bf16, loaded straight to LDS (buffer_load ... lds)
+// LDS images: mode 0 -> [plane][row][80 B]; mode 1 -> [row][192 B] with chunk swizzle kc ^= (row >> 2) & 3.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <cstring>
+#include <cmath>
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+__device__ __forceinline__ unsigned fb(float x) { return __builtin_bit_cast(unsigned, x); }
+__device__ __forceinline__ float bf(unsigned x) { return __builtin_bit_cast(float, x); }
+__device__ __forceinline__ void split3(f32x4 v, uint2& p1, uint2& p2, uint2& p3) {
+    const unsigned HI = 0xffff0000u, SEL = 0x07060302u;
+    float r[4], s[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { r[e] = v[e] - bf(fb(v[e]) & HI); s[e] = r[e] - bf(fb(r[e]) & HI); }
+    p1.x = __builtin_amdgcn_perm(fb(v[1]), fb(v[0]), SEL); p1.y = __builtin_amdgcn_perm(fb(v[3]), fb(v[2]), SEL);
+    p2.x = __builtin_amdgcn_perm(fb(r[1]), fb(r[0]), SEL); p2.y = __builtin_amdgcn_perm(fb(r[3]), fb(r[2]), SEL);
+    p3.x = __builtin_amdgcn_perm(fb(s[1]), fb(s[0]), SEL); p3.y = __builtin_amdgcn_perm(fb(s[3]), fb(s[2]), SEL);
+}
+
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rs, char* dst, unsigned voff, unsigned soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)dst, 16, voff, soff, 0, 0);
+}
+
+template <int ROWS, int MODE> struct Img { static constexpr int bytes = MODE ? ROWS * 192 : 3 * ROWS * 80; };
+
+// fragment address of (tile row R, plane p, k16-step s, lane half h)
+template <int ROWS, int MODE>
+__device__ __forceinline__ int frag_off(int R, int p, int s, int h) {
+    if (MODE) return R * 192 + p * 64 + (((2 * s + h) ^ ((R >> 2) & 3)) << 4);
+    return p * ROWS * 80 + R * 80 + s * 32 + h * 16;
+}
+
+template <int WM, int WN, int WAVES_M, int WAVES_N, int AMODE, int BMODE, int ABL>
+__global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void k(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int M, int N, int K,
+                                        const unsigned short* __restrict__ Ap, const unsigned short* __restrict__ Bp) {
+    constexpr int BM = WAVES_M * WM * 32, BN = WAVES_N * WN * 32, NT = WAVES_M * WAVES_N * 64;
+    constexpr int IA = Img<BM, AMODE>::bytes, IB = Img<BN, BMODE>::bytes;
+    __shared__ __attribute__((aligned(16))) char lds[IA + IB];
+    char* As = lds; char* Bs = lds + IA;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, r = lane & 31, h = lane >> 5;
+    const int wm0 = (wave / WAVES_N) * WM * 32, wn0 = (wave % WAVES_N) * WN * 32;
+    const int tiles_n = N / BN;
+    const int bm0 = (blockIdx.x / tiles_n) * BM, bn0 = (blockIdx.x % tiles_n) * BN;
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+
+    const long rowbytes_p = (long)K * 6;
+    const __amdgpu_buffer_rsrc_t rsA32 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A), 0, (int)((long)M * K * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB32 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(B), 0, (int)((long)N * K * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsAp = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(Ap), 0, (int)((long)M * rowbytes_p), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsBp = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(Bp), 0, (int)((long)N * rowbytes_p), 0x00020000);
+
+    // ---- mode 0 staging: thread t loads float4 at (row = p*(NT/8) + t/8, k = (t%8)*4)
+    constexpr int RPP = NT / 8;
+    f32x4 sa[AMODE ? 1 : BM / RPP], sb[BMODE ? 1 : BN / RPP];
+    unsigned oa[AMODE ? 1 : BM / RPP], ob[BMODE ? 1 : BN / RPP];
+    if (!AMODE) {
+#pragma unroll
+        for (int p = 0; p < BM / RPP; ++p) oa[p] = (unsigned)(((long)(bm0 + p * RPP + (t >> 3)) * K + ((t & 7) << 2)) << 2);
+    }
+    if (!BMODE) {
+#pragma unroll
+        for (int p = 0; p < BN / RPP; ++p) ob[p] = (unsigned)(((long)(bn0 + p * RPP + (t >> 3)) * K + ((t & 7) << 2)) << 2);
+    }
+    // ---- mode 1 staging: chunk c = i*NT + t of the [rows][12 chunks] image
+    constexpr int CA = (BM * 12 + NT - 1) / NT, CB = (BN * 12 + NT - 1) / NT;      // (rows * 12) % 64 == 0: whole waves only
+    unsigned pa[AMODE ? CA : 1], pb[BMODE ? CB : 1];
+    if (AMODE) {
+#pragma unroll
+        for (int i = 0; i < CA; ++i) {
+            const int c = i * NT + t, row = c / 12, w = c % 12, p = w >> 2, kc = (w & 3) ^ ((row >> 2) & 3);
+            pa[i] = (unsigned)((long)(bm0 + row) * rowbytes_p + p * 64 + kc * 16);
+        }
+    }
+    if (BMODE) {
+#pragma unroll
+        for (int i = 0; i < CB; ++i) {
+            const int c = i * NT + t, row = c / 12, w = c % 12, p = w >> 2, kc = (w & 3) ^ ((row >> 2) & 3);
+            pb[i] = (unsigned)((long)(bn0 + row) * rowbytes_p + p * 64 + kc * 16);
+        }
+    }
+    auto gload = [&](int kt) {      // register-staged operands: issue loads for k-tile kt
+        if (!AMODE) {
+#pragma unroll
+            for (int p = 0; p < BM / RPP; ++p) sa[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA32, oa[p], kt * 128, 0));
+        }
+        if (!BMODE) {
+#pragma unroll
+            for (int p = 0; p < BN / RPP; ++p) sb[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB32, ob[p], kt * 128, 0));
+        }
+    };
+    auto dma = [&](int kt) {        // plane operands: direct-to-LDS loads for k-tile kt
+        if (AMODE) {
+#pragma unroll
+            for (int i = 0; i < CA; ++i)
+                if (i * NT + wave * 64 < BM * 12) dma16(rsAp, As + (i * NT + wave * 64) * 16, pa[i], kt * 192);
+        }
+        if (BMODE) {
+#pragma unroll
+            for (int i = 0; i < CB; ++i)
+                if (i * NT + wave * 64 < BN * 12) dma16(rsBp, Bs + (i * NT + wave * 64) * 16, pb[i], kt * 192);
+        }
+    };
+    auto lstore = [&]() {
+        if (!AMODE) {
+#pragma unroll
+            for (int p = 0; p < BM / RPP; ++p) {
+                uint2 p1, p2, p3; split3(sa[p], p1, p2, p3);
+                const int off = (p * RPP + (t >> 3)) * 80 + ((t & 7) << 3);
+                *(uint2*)(As + off) = p1; *(uint2*)(As + BM * 80 + off) = p2; *(uint2*)(As + 2 * BM * 80 + off) = p3;
+            }
+        }
+        if (!BMODE) {
+#pragma unroll
+            for (int p = 0; p < BN / RPP; ++p) {
+                uint2 p1, p2, p3; split3(sb[p], p1, p2, p3);
+                const int off = (p * RPP + (t >> 3)) * 80 + ((t & 7) << 3);
+                *(uint2*)(Bs + off) = p1; *(uint2*)(Bs + BN * 80 + off) = p2; *(uint2*)(Bs + 2 * BN * 80 + off) = p3;
+            }
+        }
+    };
+    auto mfma_tile = [&]() {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 a[WM][3], b[WN][3];
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) a[i][pl] = *(const bf16x8*)(As + frag_off<BM, AMODE>(wm0 + i * 32 + r, pl, ks, h));
+#pragma unroll
+            for (int j = 0; j < WN; ++j)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) b[j][pl] = *(const bf16x8*)(Bs + frag_off<BN, BMODE>(wn0 + j * 32 + r, pl, ks, h));
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j) {
+                    f32x16 c = acc[i][j];
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], c, 0, 0, 0);
+                    acc[i][j] = c;
+                }
+        }
+    };
+    const int nk = K / 32;
+    gload(0); dma(0); lstore();
+    __syncthreads();            // (its fence waits for the LDS-DMA: vmcnt(0))
+    for (int kt = 0; kt + 1 < nk; ++kt) {
+        if (!(ABL & 2)) gload(kt + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (!(ABL & 4)) mfma_tile();
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        if (!(ABL & 2)) { dma(kt + 1); lstore(); }
+        __syncthreads();
+    }
+    if (!(ABL & 4)) mfma_tile();
+    if (ABL & 1) {
+        float sacc = 0.f;
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) sacc += acc[i][j][v];
+        if (sacc == 12345.678f) C[t] = sacc;
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+            const int n = bn0 + wn0 + j * 32 + r;
+            float* d = C + (long)(bm0 + wm0 + i * 32 + 4 * h) * N + n;
+            if (bm0 + wm0 + i * 32 + 31 < M) {
+#pragma unroll
+                for (int v = 0; v < 16; ++v) { *d = acc[i][j][v]; d += (((v & 3) == 3) ? 5 : 1) * (long)N; }
+            } else {
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const int m = bm0 + wm0 + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
+                    if (m < M) C[(long)m * N + n] = acc[i][j][v];
+                }
+            }
+        }
+}
+
+static float* g_ref = nullptr;
+template <int WM, int WN, int WAVES_M, int WAVES_N, int AMODE, int BMODE, int ABL = 0>
+void run(const float* A, const float* B, float* C, int M, int N, int K, const unsigned short* Ap, const unsigned short* Bp) {
+    constexpr int BM = WAVES_M * WM * 32, BN = WAVES_N * WN * 32, NT = WAVES_M * WAVES_N * 64;
+    if (N % BN) { printf("  tile %3dx%-3d skipped (N %% BN)\n", BM, BN); return; }
+    dim3 grid(((M + BM - 1) / BM) * (N / BN));
+    auto go = [&]() { hipLaunchKernelGGL((k<WM, WN, WAVES_M, WAVES_N, AMODE, BMODE, ABL>), grid, dim3(NT), 0, 0, A, B, C, M, N, K, Ap, Bp); };
+    hipMemset(C, 0, (size_t)M * N * 4);
+    go(); hipDeviceSynchronize();
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { printf("  launch error %s\n", hipGetErrorString(e)); return; }
+    // check against the reference result (first 64 rows + last 64 rows)
+    double md = 0;
+    if (g_ref) {
+        std::vector<float> c1((size_t)64 * N), c2((size_t)64 * N);
+        for (int part = 0; part < 2; ++part) {
+            const size_t off = part ? (size_t)(M - 64) * N : 0;
+            hipMemcpy(c1.data(), C + off, c1.size() * 4, hipMemcpyDeviceToHost);
+            hipMemcpy(c2.data(), g_ref + off, c2.size() * 4, hipMemcpyDeviceToHost);
+            for (size_t i = 0; i < c1.size(); ++i) md = fmax(md, fabs((double)c1[i] - c2[i]));
+        }
+    }
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    float best = 1e9;
+    for (int rr = 0; rr < 6; ++rr) { hipEventRecord(e0); for (int i = 0; i < 10; ++i) go(); hipEventRecord(e1); hipEventSynchronize(e1); float ms; hipEventElapsedTime(&ms, e0, e1); if (ms / 10 < best) best = ms / 10; }
+    printf("  abl %d A=%s B=%s tile %3dx%-3d thr %3d grid %5d: %7.1f us  %6.1f TF(f32-eq)  maxdiff %.3g\n", ABL, AMODE ? "planes" : "fp32  ", BMODE ? "planes" : "fp32  ", BM, BN, NT, grid.x,
+           best * 1e3, 2.0 * M * N * K / best / 1e9, md);
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// v2: both operands as planes in layout i16 = [row][K/16][3 planes][16] bf16 (96 B per row and k16-stage),
+// two-slot LDS ring filled by LDS-DMA one stage ahead (stage s+1 lands under the MFMAs of stage s), ONE barrier
+// per stage, swapped MFMA operands (accumulator = C^T tile: a lane owns one output row and 4 x 4 consecutive
+// columns -> 16-byte stores).
+template <int WM, int WN, int WAVES_M, int WAVES_N, int ABL>
+__global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void kp(float* __restrict__ C, int M, int N, int K,
+                                                              const unsigned short* __restrict__ Ap, const unsigned short* __restrict__ Bp) {
+    constexpr int BM = WAVES_M * WM * 32, BN = WAVES_N * WN * 32, NT = WAVES_M * WAVES_N * 64, NW = NT / 64;
+    constexpr int SA = BM * 96, SB = BN * 96, SLOT = SA + SB;
+    __shared__ __attribute__((aligned(16))) char lds[2 * SLOT];
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), r = lane & 31, h = lane >> 5;
+    const int wm0 = (wave / WAVES_N) * WM * 32, wn0 = (wave % WAVES_N) * WN * 32;
+    const int tiles_n = N / BN;
+    const int bm0 = (blockIdx.x / tiles_n) * BM, bn0 = (blockIdx.x % tiles_n) * BN;
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+    const unsigned rowbytes = (unsigned)K * 6;
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(Ap), 0, (int)((long)M * rowbytes), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(Bp), 0, (int)((long)N * rowbytes), 0x00020000);
+    // DMA pieces: q < QA -> A chunks [64q, 64q+64), else B chunks; wave w issues q = w, w + NW, ...
+    constexpr int QA = BM * 6 / 64, QB = BN * 6 / 64, QT = QA + QB, QW = (QT + NW - 1) / NW;
+    unsigned voff[QW];
+#pragma unroll
+    for (int i = 0; i < QW; ++i) {
+        const int q = wave + i * NW;
+        const bool isA = q < QA;
+        const int c = (isA ? q : q - QA) * 64 + lane, row = c / 6, w = c % 6, pl = w >> 1, kc = (w & 1) ^ ((row >> 3) & 1);
+        voff[i] = (unsigned)((isA ? bm0 : bn0) + row) * rowbytes + pl * 32 + kc * 16;
+    }
+    auto dma = [&](int s) {
+        char* slot = lds + (s & 1) * SLOT;
+#pragma unroll
+        for (int i = 0; i < QW; ++i) {
+            const int q = wave + i * NW;
+            if (q < QA) dma16(rsA, slot + q * 1024, voff[i], s * 96);
+            else if (q < QT) dma16(rsB, slot + SA + (q - QA) * 1024, voff[i], s * 96);
+        }
+    };
+    // fragment byte offsets inside a slot (A image at 0, B image at SA)
+    int fa[WM], fbo[WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i) { const int R = wm0 + i * 32 + r; fa[i] = R * 96 + ((h ^ ((R >> 3) & 1)) << 4); }
+#pragma unroll
+    for (int j = 0; j < WN; ++j) { const int R = wn0 + j * 32 + r; fbo[j] = SA + R * 96 + ((h ^ ((R >> 3) & 1)) << 4); }
+    auto mfma_stage = [&](int s) {
+        const char* slot = lds + (s & 1) * SLOT;
+        bf16x8 a[WM][3], b[WN][3];
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) a[i][pl] = *(const bf16x8*)(slot + fa[i] + pl * 32);
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) b[j][pl] = *(const bf16x8*)(slot + fbo[j] + pl * 32);
+        if (ABL & 4) return;
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j) {
+                f32x16 c = acc[i][j];       // C^T tile: first operand = B rows (n), second = A rows (m)
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j][0], a[i][2], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j][2], a[i][0], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j][1], a[i][1], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j][0], a[i][1], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j][1], a[i][0], c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[j][0], a[i][0], c, 0, 0, 0);
+                acc[i][j] = c;
+            }
+    };
+    const int ns = K / 16;
+    dma(0);
+    for (int s = 0; s < ns; ++s) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (s + 1 < ns && !(ABL & 2)) dma(s + 1);
+        mfma_stage(s);
+    }
+    if (ABL & 1) {
+        float sacc = 0.f;
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) sacc += acc[i][j][v];
+        if (sacc == 12345.678f) C[t] = sacc;
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < WM; ++i) {
+        const int m = bm0 + wm0 + i * 32 + r;
+        if (m >= M) continue;
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+            float* d = C + (long)m * N + bn0 + wn0 + j * 32 + 4 * h;
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *(f32x4*)(d + 8 * g) = f32x4{acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+        }
+    }
+}
+
+static float* g_ref2 = nullptr;
+template <int WM, int WN, int WAVES_M, int WAVES_N, int ABL = 0>
+void runp(float* C, int M, int N, int K, const unsigned short* Ap, const unsigned short* Bp) {
+    constexpr int BM = WAVES_M * WM * 32, BN = WAVES_N * WN * 32, NT = WAVES_M * WAVES_N * 64;
+    if (N % BN) { printf("  v2 tile %3dx%-3d skipped (N %% BN)\n", BM, BN); return; }
+    dim3 grid(((M + BM - 1) / BM) * (N / BN));
+    auto go = [&]() { hipLaunchKernelGGL((kp<WM, WN, WAVES_M, WAVES_N, ABL>), grid, dim3(NT), 0, 0, C, M, N, K, Ap, Bp); };
+    hipMemset(C, 0, (size_t)M * N * 4);
+    go(); hipDeviceSynchronize();
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { printf("  launch error %s\n", hipGetErrorString(e)); return; }
+    double md = 0;
+    if (g_ref2) {
+        std::vector<float> c1((size_t)64 * N), c2((size_t)64 * N);
+        for (int part = 0; part < 2; ++part) {
+            const size_t off = part ? (size_t)(M - 64) * N : 0;
+            hipMemcpy(c1.data(), C + off, c1.size() * 4, hipMemcpyDeviceToHost);
+            hipMemcpy(c2.data(), g_ref2 + off, c2.size() * 4, hipMemcpyDeviceToHost);
+            for (size_t i = 0; i < c1.size(); ++i) md = fmax(md, fabs((double)c1[i] - c2[i]));
+        }
+    }
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    float best = 1e9;
+    for (int rr = 0; rr < 6; ++rr) { hipEventRecord(e0); for (int i = 0; i < 10; ++i) go(); hipEventRecord(e1); hipEventSynchronize(e1); float ms; hipEventElapsedTime(&ms, e0, e1); if (ms / 10 < best) best = ms / 10; }
+    printf("  v2 abl %d tile %3dx%-3d thr %3d grid %5d: %7.1f us  %6.1f TF(f32-eq)  maxdiff %.3g\n", ABL, BM, BN, NT, grid.x, best * 1e3, 2.0 * M * N * K / best / 1e9, md);
+}
+
+static void split_host16(const std::vector<float>& h, size_t rows, int K, std::vector<unsigned short>& out) {
+    out.assign(rows * K * 3, 0);
+    for (size_t rw = 0; rw < rows; ++rw)
+        for (int kk = 0; kk < K; ++kk) {
+            float v = h[rw * K + kk]; unsigned u; memcpy(&u, &v, 4); unsigned short a = u >> 16; unsigned ua = (unsigned)a << 16; float fa; memcpy(&fa, &ua, 4);
+            float r1 = v - fa; memcpy(&u, &r1, 4); unsigned short b2 = u >> 16; unsigned ub = (unsigned)b2 << 16; float fb_; memcpy(&fb_, &ub, 4);
+            float r2 = r1 - fb_; memcpy(&u, &r2, 4); unsigned short c3 = u >> 16;
+            const size_t base = rw * (size_t)K * 3 + (size_t)(kk >> 4) * 48 + (kk & 15);
+            out[base] = a; out[base + 16] = b2; out[base + 32] = c3;
+        }
+}
+
+static void split_host(const std::vector<float>& h, size_t rows, int K, std::vector<unsigned short>& out) {
+    out.assign(rows * K * 3, 0);
+    for (size_t rw = 0; rw < rows; ++rw)
+        for (int kk = 0; kk < K; ++kk) {
+            float v = h[rw * K + kk]; unsigned u; memcpy(&u, &v, 4); unsigned short a = u >> 16; unsigned ua = (unsigned)a << 16; float fa; memcpy(&fa, &ua, 4);
+            float r1 = v - fa; memcpy(&u, &r1, 4); unsigned short b2 = u >> 16; unsigned ub = (unsigned)b2 << 16; float fb_; memcpy(&fb_, &ub, 4);
+            float r2 = r1 - fb_; memcpy(&u, &r2, 4); unsigned short c3 = u >> 16;
+            const size_t base = rw * (size_t)K * 3 + (size_t)(kk >> 5) * 96 + (kk & 31);
+            out[base] = a; out[base + 32] = b2; out[base + 64] = c3;
+        }
+}
+
+int main(int argc, char** argv) {
+    const int M = argc > 1 ? atoi(argv[1]) : 33280, N = argc > 2 ? atoi(argv[2]) : 576, K = argc > 3 ? atoi(argv[3]) : 192;
+    float *A, *B, *C, *R; hipMalloc(&A, (size_t)M * K * 4); hipMalloc(&B, (size_t)N * K * 4); hipMalloc(&C, (size_t)M * N * 4); hipMalloc(&R, (size_t)M * N * 4);
+    std::vector<float> ha((size_t)M * K), hb((size_t)N * K);
+    unsigned s = 12345u;
+    auto rnd = [&]() { s = s * 1664525u + 1013904223u; return ((float)((s >> 8) & 0xffff) / 65536.f - 0.5f) * (1.f + (float)(s >> 28)); };
+    for (auto& v : ha) v = rnd();
+    for (auto& v : hb) v = rnd();
+    hipMemcpy(A, ha.data(), ha.size() * 4, hipMemcpyHostToDevice); hipMemcpy(B, hb.data(), hb.size() * 4, hipMemcpyHostToDevice);
+    std::vector<unsigned short> pa, pb; split_host(ha, M, K, pa); split_host(hb, N, K, pb);
+    unsigned short *Ap, *Bp; hipMalloc(&Ap, pa.size() * 2); hipMalloc(&Bp, pb.size() * 2);
+    hipMemcpy(Ap, pa.data(), pa.size() * 2, hipMemcpyHostToDevice); hipMemcpy(Bp, pb.data(), pb.size() * 2, hipMemcpyHostToDevice);
+    printf("M=%d N=%d K=%d  (%.2f GFLOP f32-eq; ceiling 416.7 TF)\n", M, N, K, 2.0 * M * N * K / 1e9);
+    // reference: the round-1 configuration (64x64, both split in-kernel)
+    run<1, 1, 2, 2, 0, 0>(A, B, R, M, N, K, Ap, Bp); g_ref = R;
+    run<2, 3, 2, 2, 1, 1, 0>(A, B, C, M, N, K, Ap, Bp);
+    std::vector<unsigned short> pa16, pb16; split_host16(ha, M, K, pa16); split_host16(hb, N, K, pb16);
+    hipMemcpy(Ap, pa16.data(), pa16.size() * 2, hipMemcpyHostToDevice); hipMemcpy(Bp, pb16.data(), pb16.size() * 2, hipMemcpyHostToDevice);
+    g_ref2 = R;
+    runp<2, 3, 2, 2, 0>(C, M, N, K, Ap, Bp);
+    runp<2, 3, 2, 2, 1>(C, M, N, K, Ap, Bp);
+    runp<2, 3, 2, 2, 2>(C, M, N, K, Ap, Bp);
+    runp<2, 3, 2, 2, 3>(C, M, N, K, Ap, Bp);
+    runp<2, 3, 2, 2, 4>(C, M, N, K, Ap, Bp);
+    runp<2, 3, 2, 2, 6>(C, M, N, K, Ap, Bp);
+    runp<1, 3, 2, 2, 0>(C, M, N, K, Ap, Bp);
+    runp<1, 3, 2, 2, 1>(C, M, N, K, Ap, Bp);
+    runp<1, 3, 2, 2, 3>(C, M, N, K, Ap, Bp);
+    runp<2, 3, 1, 2, 0>(C, M, N, K, Ap, Bp);      // 64x192 with 2 waves
+    runp<1, 3, 4, 2, 0>(C, M, N, K, Ap, Bp);      // 128x192, 8 waves
+    runp<2, 3, 4, 2, 0>(C, M, N, K, Ap, Bp);      // 256x192, 8 waves
+    runp<2, 3, 4, 2, 1>(C, M, N, K, Ap, Bp);
+    return 0;
+}

@@ -6,8 +6,9 @@ OUT="${1:-$HERE/..}"
 mkdir -p "$HERE/obj"
 FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wall -Wno-unused-function"
 pids=()
+newest_h="$(ls -t "$HERE"/*.h "$HERE/../../include/vitsom_hip.h" | head -1)"
 for f in gemm_f32 som som_l1 layernorm attention misc; do
-  if [ ! -f "$HERE/obj/$f.o" ] || [ "$HERE/$f.hip" -nt "$HERE/obj/$f.o" ] || [ "$HERE/gemm_f32.h" -nt "$HERE/obj/$f.o" ] || [ "$HERE/gemm_x6.h" -nt "$HERE/obj/$f.o" ] || [ "$HERE/common.h" -nt "$HERE/obj/$f.o" ] || [ "$HERE/../../include/vitsom_hip.h" -nt "$HERE/obj/$f.o" ]; then
+  if [ ! -f "$HERE/obj/$f.o" ] || [ "$HERE/$f.hip" -nt "$HERE/obj/$f.o" ] || [ "$newest_h" -nt "$HERE/obj/$f.o" ]; then
     hipcc $FLAGS -c "$HERE/$f.hip" -o "$HERE/obj/$f.o" &
     pids+=($!)
   fi

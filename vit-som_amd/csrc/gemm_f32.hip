@@ -1,6 +1,7 @@
 // GEMM launcher + the nn.Linear-shaped C-ABI entries built on it.
 #include "gemm_f32.h"
 #include "gemm_x6.h"
+#include "gemm_x6_tn.h"
 
 #include <atomic>
 
@@ -249,8 +250,25 @@ int choose_splits(int tiles, int ktiles, int max_splits, bool prefer_xcd_multipl
     }
     return best_s;
 }
-static int bwd_weight_splits(int M, int N, int K) {
-    return choose_splits(cdiv(N, gemm_tile_m(false, false, N)) * cdiv(K, 64), cdiv(M, 32), 128);
+// Weight-gradient plan: tile configuration of gemm_x6_tn_kernel (0 = none fits: the generic k-strided
+// kernel) and the number of reduction splits -- a function of the shape only, so that the workspace
+// query and the launch agree.
+struct TnPlan { int cfg; int splits; };
+static TnPlan bwd_weight_plan(int M, int N, int K) {
+    TnPlan p;
+    p.cfg = (N % 192 == 0 && K % 64 == 0) ? 1 : (N % 96 == 0 && K % 96 == 0) ? 2 : 0;
+    if (p.cfg == 0) {
+        p.splits = choose_splits(cdiv(N, gemm_tile_m(false, false, N)) * cdiv(K, 64), cdiv(M, 32), 128);
+        return p;
+    }
+    const int tiles = p.cfg == 1 ? (N / 192) * (K / 64) : (N / 96) * (K / 96);
+    const int ktiles = cdiv(M, 32);
+    int s = (512 + tiles / 2) / tiles;                // two resident workgroups per CU
+    if (s > ktiles) s = ktiles;
+    if (s < 1) s = 1;
+    const int per = cdiv(ktiles, s);
+    p.splits = cdiv(ktiles, per);
+    return p;
 }
 static long pad4(long n) { return (n + 3) & ~3L; }
 
@@ -265,9 +283,31 @@ int linear_bwd_weight_impl(const float* dY, long lddy, const float* X, long ldx,
                  "linear_bwd_weight: workspace too small (%zu < %zu)", ws_bytes,
                  vsom_linear_bwd_weight_workspace_bytes(M, N, K));
     VSOM_REQUIRE(aligned16(ws), VSOM_EALIGN, "linear_bwd_weight: workspace must be 16-byte aligned");
-    const int splits = bwd_weight_splits(M, N, K);
+    const TnPlan plan = bwd_weight_plan(M, N, K);
+    const int splits = plan.splits;
     const long wlen = pad4((long)N * K), blen = pad4(N);
     float* slab = static_cast<float*>(ws);
+    const long a_last = a_seg ? (long)((M - 1) / a_seg) * a_stride + a_off + (M - 1) % a_seg : M - 1;
+    const long ab = (a_last * lddy + N) * 4, bb = ((long)(M - 1) * ldx + K) * 4;
+    const bool tn_ok = plan.cfg != 0 && gemm_mode() == VSOM_GEMM_SPLIT_BF16 && aligned16(dY) && aligned16(X) &&
+                       lddy % 4 == 0 && ldx % 4 == 0 && ab < 0xFFFF0000L && bb < 0xFFFF0000L &&
+                       (a_seg == 0 || (a_seg % 32 == 0 && M % a_seg == 0));
+    if (tn_ok) {
+        TnP t = {};
+        t.dY = dY; t.X = X; t.ldy = lddy; t.ldx = ldx; t.T = M; t.NO = N; t.KI = K;
+        t.ktiles_per_split = cdiv(cdiv(M, 32), splits);
+        t.a_seg = a_seg; t.a_stride = a_stride; t.a_off = a_off;
+        t.slab = slab; t.slab_stride = wlen + blen;
+        t.slab_bias = db ? slab + wlen : nullptr; t.slab_bias_stride = wlen + blen;
+        t.a_bytes = (unsigned)ab; t.b_bytes = (unsigned)bb;
+        if (plan.cfg == 1)
+            hipLaunchKernelGGL((gemm_x6_tn_kernel<3, 1, 2, 2>), dim3((N / 192) * (K / 64) * splits), dim3(256), 0, stream, t);
+        else
+            hipLaunchKernelGGL((gemm_x6_tn_kernel<3, 1, 1, 3>), dim3((N / 96) * (K / 96) * splits), dim3(192), 0, stream, t);
+        const int rc = hip_status(hipGetLastError(), "gemm_x6_tn_kernel");
+        if (rc) return rc;
+        return reduce_slabs2_internal(slab, wlen + blen, splits, dW, (long)N * K, db, wlen, db ? N : 0, stream);
+    }
     // GEMM rows = n, cols = k, reduction = m; both operands k-strided
     GemmP g = {};
     g.A = dY; g.lda = lddy; g.B = X; g.ldb = ldx;
@@ -277,7 +317,9 @@ int linear_bwd_weight_impl(const float* dY, long lddy, const float* X, long ldx,
     g.slab_bias = db ? slab + wlen : nullptr; g.slab_bias_stride = wlen + blen;
     int rc = launch_gemm(false, false, EPI_SLAB, g, splits, stream);
     if (rc) return rc;
-    return reduce_slabs2_internal(slab, wlen + blen, splits, dW, (long)N * K, db, wlen, db ? N : 0, stream);
+    // launch_gemm may have reduced the split count (canonical form): unused slabs were never written
+    const int used = cdiv(cdiv(M, 32), cdiv(cdiv(M, 32), splits));
+    return reduce_slabs2_internal(slab, wlen + blen, used, dW, (long)N * K, db, wlen, db ? N : 0, stream);
 }
 
 }  // namespace vsom
@@ -376,7 +418,7 @@ int vsom_get_gemm_mode(void) { return gemm_mode(); }
 
 size_t vsom_linear_bwd_weight_workspace_bytes(int M, int N, int K) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
-    const int s = bwd_weight_splits(M, N, K);
+    const int s = bwd_weight_plan(M, N, K).splits;
     return (size_t)s * (size_t)(pad4((long)N * K) + pad4(N)) * sizeof(float);
 }
 
