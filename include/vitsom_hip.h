@@ -240,6 +240,9 @@ int vsom_argmax_rows(const float* X, long ldx, int rows, int cols, int64_t* out,
 
 /* ------------------------------------------------------------------ small utilities */
 int vsom_fill(float* p, long n, float value, vsom_stream_t stream);
+/* p[i] *= *scale_dev (a device scalar: no host sync) -- the incoming gradient of loss.backward(), applied to the
+   loss-side gradient seeds before the backward kernels run (torch autograd's role at vit_som.py:80-105) */
+int vsom_scale_by(float* p, long n, const float* scale_dev, vsom_stream_t stream);
 /* out[j] = sum_s slabs[s*stride + j], j in [0,n) -- fixed summation order */
 int vsom_reduce_slabs(const float* slabs, long stride, int nslabs, float* out, long n,
                       vsom_stream_t stream);

@@ -75,6 +75,7 @@ SIGNATURES = {
     "vsom_contingency": (C.c_int, [c_fp, c_fp, C.c_long, C.c_int, C.c_int, c_fp, c_fp, c_stream]),
     "vsom_argmax_rows": (C.c_int, [c_fp, C.c_long, C.c_int, C.c_int, c_fp, c_stream]),
     "vsom_fill": (C.c_int, [c_fp, C.c_long, C.c_float, c_stream]),
+    "vsom_scale_by": (C.c_int, [c_fp, C.c_long, c_fp, c_stream]),
     "vsom_reduce_slabs": (C.c_int, [c_fp, C.c_long, C.c_int, c_fp, C.c_long, c_stream]),
 }
 

@@ -182,6 +182,11 @@ __global__ __launch_bounds__(256) void fill_kernel(float* __restrict__ p, long n
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) p[i] = value;
 }
 
+__global__ __launch_bounds__(256) void scale_by_kernel(float* __restrict__ p, long n, const float* __restrict__ s) {
+    const float v = *s;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) p[i] *= v;
+}
+
 // batched 32x32-tile transpose through LDS; blockIdx.y = tensor, blockIdx.x = tile (surplus tiles exit)
 __global__ __launch_bounds__(256) void transpose_many_kernel(const float* __restrict__ src_base, float* __restrict__ dst_base,
                                                              const long long* __restrict__ table) {
@@ -229,6 +234,13 @@ int vsom_fill(float* p, long n, float value, vsom_stream_t stream) {
     if (n == 0) return VSOM_OK;
     hipLaunchKernelGGL(fill_kernel, dim3(grid_for(n, 1024, 4096)), dim3(256), 0, stream, p, n, value);
     VSOM_LAUNCH_CHECK("fill_kernel");
+}
+
+int vsom_scale_by(float* p, long n, const float* scale_dev, vsom_stream_t stream) {
+    VSOM_REQUIRE(p && scale_dev && n >= 0, VSOM_EINVAL, "scale_by: bad arguments");
+    if (n == 0) return VSOM_OK;
+    hipLaunchKernelGGL(scale_by_kernel, dim3(grid_for(n, 1024, 4096)), dim3(256), 0, stream, p, n, scale_dev);
+    VSOM_LAUNCH_CHECK("scale_by_kernel");
 }
 
 int vsom_transpose_many(const float* src_base, float* dst_base, const long long* table, int count, int max_rows,

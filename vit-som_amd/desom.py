@@ -211,10 +211,18 @@ class DESOM(_ArenaOwner, _Base):
         return total
 
     @torch.no_grad()
+    def _scale_seeds(self, gout):
+        """Multiply the loss-side gradient seeds by the scalar `gout` (0-dim device tensor)."""
+        _, a, s = self._ctx
+        gout = gout.detach().reshape(1).float().contiguous()
+        for buf in (s.coef, s.row_dot, s.col_dot, a.dpred) + ((a.dlogits,) if self.classification else ()):
+            ops.scale_by(buf, gout)
+
+    @torch.no_grad()
     def _backward(self):
         x, a, s = self._ctx
         self._grads_reduced = False
-        self._early = None
+        self._exchange_reset()
         z = a.enc_act[-1]
         # decoder: d total / d pred sits in a.dpred
         dz_dec = self._mlp_bwd(self.autoencoder.decoder, "autoencoder.decoder", z, a.dec_act, a.dec_der, a.dpred, a, True)
@@ -225,7 +233,10 @@ class DESOM(_ArenaOwner, _Base):
             ops.som_bwd_manhattan(z, W, s.coef, gW, a.dz, accumulate_gx=True)
         else:
             ops.som_bwd(z, W, s.coef, s.row_dot, s.col_dot, gW, a.dz, accumulate_gx=True)
-        self._start_prototype_allreduce()
+        if self._overlap_enabled():
+            off, n, _ = self.arena.offsets["som_layer.prototypes"]
+            self._reduce_early(off, off + (n + 255) // 256 * 256,
+                               streams=[torch.cuda.current_stream()] if gW.is_cuda else [])
         if self.classification:
             ops.linear_bwd_weight(a.dlogits, z, self._grad_views["classifier.weight"], self._grad_views["classifier.bias"])
             ops.linear_bwd_input(a.dlogits, self.classifier.weight, a.dz, accumulate=True)

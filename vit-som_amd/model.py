@@ -434,8 +434,10 @@ class ViTAutoencoder(nn.Module):
     def _views(self, a: _Acts, dim: int):
         return [b[:a.T * dim].view(a.T, dim) for b in a.g]
 
-    def _decoder_bwd(self, a: _Acts, G, WT=None):
-        """a.dpred holds dL/dpred; writes decoder grads and dL/d(xe) into a.d_xe (overwrite)."""
+    def _decoder_bwd(self, a: _Acts, G, WT=None, before_dxe=None):
+        """a.dpred holds dL/dpred; writes decoder grads and dL/d(xe) into a.d_xe -- overwriting it, or,
+        when `before_dxe` is given, calling it and then ADDING to what a.d_xe holds (the SOM input
+        gradient written concurrently on another stream; `before_dxe` waits for it)."""
         DE = self.decoder_embed_dim
         ring = self._views(a, DE)
         gA = ring[0]
@@ -452,10 +454,13 @@ class ViTAutoencoder(nn.Module):
             gout = self._block_bwd(self.decoder_blocks[i], a.dec[i], x_in, gout, a, G, f"decoder_blocks.{i}", bufs, WT, j & 1)
             pos = (pos + 2) % 5
         ops.linear_bwd_weight(gout, a.xe, G("decoder_embed.weight"), G("decoder_embed.bias"))
-        self._dx(WT, gout, self.decoder_embed.weight, a.d_xe)
+        if before_dxe is not None:
+            before_dxe()
+        self._dx(WT, gout, self.decoder_embed.weight, a.d_xe, accumulate=before_dxe is not None)
 
-    def _encoder_bwd(self, a: _Acts, G, WT=None):
-        """a.d_xe holds dL/d(xe); writes every encoder gradient."""
+    def _encoder_bwd(self, a: _Acts, G, WT=None, on_block=None):
+        """a.d_xe holds dL/d(xe); writes every encoder gradient.  on_block(i) is called once block i's
+        backward (main chain and weight-gradient side work) has been enqueued."""
         self._side_join(keep=0)            # the decoder's blocks may still be reading the shared buffers
         E = self.embed_dim
         ring = self._views(a, E)
@@ -468,6 +473,8 @@ class ViTAutoencoder(nn.Module):
             bufs = [ring[(pos + 1) % 5], ring[(pos + 2) % 5]]
             gout = self._block_bwd(self.blocks[i], a.enc[i], x_in, gout, a, G, f"blocks.{i}", bufs, WT, j & 1)
             pos = (pos + 2) % 5
+            if on_block is not None:
+                on_block(i)
         p = self.patch_embed.patch_size[0]
         ops.patch_embed_bwd(gout, a.xp, G("patch_embed.proj.weight").view(E, -1), G("patch_embed.proj.bias"),
                             G("cls_token").view(E), a.B, self.in_chans, self.img_size, p, E)
@@ -644,7 +651,10 @@ class FusedAdamW(torch.optim.Optimizer):
 
     @torch.no_grad()
     def step(self, closure=None):
-        loss = closure() if closure is not None else None
+        loss = None
+        if closure is not None:               # Lightning's automatic optimization passes training_step + backward here
+            with torch.enable_grad():
+                loss = closure()
         m = self._model
         m.allreduce_gradients()
         self._step += 1
@@ -708,7 +718,9 @@ class FusedAdamW(torch.optim.Optimizer):
 class _StepLoss(torch.autograd.Function):
     """Makes the fused step look like one differentiable scalar to torch / Lightning:
     forward = all HIP forward kernels + losses, backward = all HIP backward kernels writing the
-    gradient arena (then scaled by the incoming scalar gradient)."""
+    gradient arena.  The incoming scalar gradient multiplies the three loss-side seeds (dL/dpred,
+    dL/dlogits, the SOM coefficients) BEFORE the backward kernels run -- the backward is linear in
+    them -- so nothing touches the arena after the overlapped all-reduces have started."""
 
     @staticmethod
     def forward(ctx, anchor, model, x, y, gamma_t, T):
@@ -718,8 +730,8 @@ class _StepLoss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gout):
         m = ctx.model
+        m._scale_seeds(gout)               # 1.0 under a plain loss.backward()
         m._backward()
-        m.arena.grads.mul_(gout)           # 1.0 under a plain loss.backward()
         m._expose_grads()
         return None, None, None, None, None, None
 
@@ -733,7 +745,6 @@ class _ArenaOwner:
     arena: Optional[ParamArena] = None
     world_size, rank = 1, 0
     _grads_reduced = False
-    _early = None
 
     def _default_weight_decay(self, name: str, p) -> float:
         return 0.0
@@ -788,53 +799,85 @@ class _ArenaOwner:
         self.world_size, self.rank = int(world_size), int(rank)
         self.som_layer._world_size = int(world_size)
 
+    # -- data-parallel exchange: sum all-reduce over the gradient arena, in pieces -----------------
+    # Each piece is a contiguous arena slice whose gradients are final at a known point of the backward
+    # pass: the [K, L] prototype accumulator right after the SOM backward (79 of 100 MB at CIFAR shapes),
+    # the decoder after the decoder backward, the encoder in buckets of a few blocks in reverse layer
+    # order.  A piece is issued from a stream of its own that first waits for the events of the streams
+    # that wrote it (main chain + weight-gradient side stream), so the collective (RCCL runs it on its
+    # own stream) overlaps the rest of the backward; allreduce_gradients() reduces what is left and
+    # makes the consumer stream wait for every piece.  Under torch.distributed "nccl" == RCCL over xGMI.
     def _overlap_enabled(self) -> bool:
-        import os
         return self.world_size > 1 and os.environ.get("VSOM_OVERLAP_ALLREDUCE", "1") != "0"
 
-    def _start_prototype_allreduce(self):
-        """Called inside the backward pass right after the SOM backward: the [K, L] prototype
-        gradient (the bulk of the exchange: 79 MB of 100 MB at CIFAR shapes) is final, while the
-        whole encoder backward is still to run -- start its all-reduce now (RCCL runs it on its own
-        stream, ordered after the kernels already queued) and let it finish under those kernels."""
-        self._early = None
+    def _exchange_reset(self):
+        self._works, self._started = [], []
+
+    def _arena_span(self, first: str, last: str):
+        """[lo, hi) of the arena slice from parameter `first` through parameter `last` (padded)."""
+        lo = self.arena.offsets[first][0]
+        off, n, _ = self.arena.offsets[last]
+        return lo, off + (n + 255) // 256 * 256
+
+    def _reduce_async(self, lo: int, hi: int, after=()):
+        """Start the sum all-reduce of grads[lo:hi]; `after` = events the piece must wait for."""
+        import torch.distributed as dist
+        g = self.arena.grads
+        if hi <= lo:
+            return
+        if g.is_cuda:
+            comm = getattr(self, "_comm", None)
+            if comm is None or comm.device != g.device:
+                comm = self._comm = torch.cuda.Stream(device=g.device)
+            for ev in after:
+                comm.wait_event(ev)
+            with torch.cuda.stream(comm):
+                work = dist.all_reduce(g[lo:hi], op=dist.ReduceOp.SUM, async_op=True)
+        else:
+            work = dist.all_reduce(g[lo:hi], op=dist.ReduceOp.SUM, async_op=True)
+        self._works.append(work)
+        self._started.append((lo, hi))
+
+    def _reduce_early(self, lo: int, hi: int, streams=()):
+        """Called inside the backward pass once grads[lo:hi] is final on the given streams."""
         if not self._overlap_enabled():
             return
-        import torch.distributed as dist
-        g = self.arena.grads
-        off, n, _ = self.arena.offsets["som_layer.prototypes"]
-        piece = g[off:off + n]
-        if g.is_cuda and dist.get_backend() == "gloo":
-            return                                   # CPU rehearsal backend: exchanged with the rest, staged through the host
-        self._early = (off, n, dist.all_reduce(piece, op=dist.ReduceOp.SUM, async_op=True))
+        evs = []
+        if self.arena.grads.is_cuda:
+            for st in streams:
+                ev = torch.cuda.Event()
+                ev.record(st)
+                evs.append(ev)
+        self._reduce_async(lo, hi, evs)
 
     def allreduce_gradients(self):
-        """Sum the gradient arena (ViT grads + prototype accumulators) across ranks (RCCL over xGMI
-        under the "nccl" backend); AdamW divides by world_size.  The prototype slice may already be
-        in flight (see _start_prototype_allreduce); the rest goes in one call per contiguous piece.
-        Under the gloo backend (CPU rehearsal of the N > 1 path) device tensors are staged through
-        the host."""
+        """Reduce every arena slice not yet in flight, then make the current stream wait for all pieces.
+        Idempotent until the next backward pass; AdamW divides by world_size."""
         if self.world_size <= 1 or self._grads_reduced:
             return
-        self._grads_reduced = True            # idempotent until the next backward pass
-        import torch.distributed as dist
+        self._grads_reduced = True
         g = self.arena.grads
-        early, self._early = getattr(self, "_early", None), None
-        if g.is_cuda and dist.get_backend() == "gloo":
-            host = g.cpu()
-            dist.all_reduce(host, op=dist.ReduceOp.SUM)
-            g.copy_(host)
-            return
-        if early is None:
-            dist.all_reduce(g, op=dist.ReduceOp.SUM)
-            return
-        off, n, work = early
-        if off > 0:
-            dist.all_reduce(g[:off], op=dist.ReduceOp.SUM)
-        if off + n < g.numel():
-            dist.all_reduce(g[off + n:], op=dist.ReduceOp.SUM)
-        work.wait()                            # the consumer stream now waits for the early piece
+        if not hasattr(self, "_works"):
+            self._exchange_reset()
+        evs = []
+        if g.is_cuda:
+            ev = torch.cuda.Event()
+            ev.record()                         # current stream: every gradient is final here
+            evs.append(ev)
+        pos = 0
+        for lo, hi in sorted(self._started) + [(g.numel(), g.numel())]:
+            if lo > pos:
+                self._reduce_async(pos, lo, evs)
+            pos = max(pos, hi)
+        for w in self._works:
+            w.wait()                            # nccl: the current stream waits; gloo: the host does
+        self._exchange_reset()
 
+    def broadcast_parameters(self, src: int = 0):
+        """Replicas are built from the same seed; this makes it explicit (DDP broadcasts at construction)."""
+        if self.world_size > 1:
+            import torch.distributed as dist
+            dist.broadcast(self.arena.params, src=src)
 
 
 # ------------------------------------------------------------------------------------ ViT-SOM
@@ -1037,11 +1080,38 @@ class ViTSOM(_ArenaOwner, _Base):
         self.vit.__dict__["_lent_stream"] = self._side_stream
 
     @torch.no_grad()
+    def _scale_seeds(self, gout):
+        """Multiply the loss-side gradient seeds by the scalar `gout` (a 0-dim device tensor)."""
+        _, a, s = self._ctx
+        gout = gout.detach().reshape(1).float().contiguous()
+        for buf in ((s.coef, s.row_dot, s.col_dot) + ((a.dlogits,) if self.classification else (a.dpred,))):
+            ops.scale_by(buf, gout)
+
+    def _exchange_buckets(self):
+        """Arena slices reduced early, in the order the backward finishes them: name -> (lo, hi)."""
+        b = self.__dict__.get("_bucket_cache")
+        if b is not None and b[0] is self.arena:
+            return b[1]
+        names = [n for n, _ in self._named_trainable()]
+        out = {"som": (self.arena.offsets["som_layer.prototypes"][0], self.arena.numel)}
+        dec = [n for n in names if n.startswith("vit.decoder_")]
+        if dec and not self.classification:
+            out["decoder"] = self._arena_span(dec[0], dec[-1])
+        D = len(self.vit.blocks)
+        step = max(1, int(os.environ.get("VSOM_BUCKET_BLOCKS", "3")))
+        hi_name = "vit.norm.bias"
+        for i in range(D - step, 0, -step):                 # blocks [i, i + step) (+ the final norm for the top bucket)
+            out[f"enc{i}"] = self._arena_span(f"vit.blocks.{i}.norm1.weight", hi_name)
+            hi_name = f"vit.blocks.{i - 1}.mlp.2.bias"
+        self.__dict__["_bucket_cache"] = (self.arena, out)
+        return out
+
+    @torch.no_grad()
     def _backward(self):
         """All backward kernels; overwrites the whole gradient arena (no accumulation)."""
         x, a, s = self._ctx
         self._grads_reduced = False
-        self._early = None
+        self._exchange_reset()
         if x.is_cuda and os.environ.get("VSOM_SIDE_STREAM", "1") != "0":
             self._ensure_streams(x.device)
             self.vit._side = self._side_stream
@@ -1055,6 +1125,8 @@ class ViTSOM(_ArenaOwner, _Base):
             gX = torch.as_strided(a.d_xe, (a.B, E), (N * E, 1), a.d_xe.storage_offset())
         else:
             gX = torch.as_strided(a.d_xe, (a.B, (N - 1) * E), (N * E, 1), a.d_xe.storage_offset() + E)
+        buckets = self._exchange_buckets() if self._overlap_enabled() else {}
+        main = torch.cuda.current_stream() if x.is_cuda else None
 
         def som_backward(gx_out, accumulate):
             if self.som_layer._dist_mode == ops.DIST_MANHATTAN:
@@ -1063,6 +1135,9 @@ class ViTSOM(_ArenaOwner, _Base):
             else:
                 ops.som_bwd(X, self.som_layer.prototypes, s.coef, s.row_dot, s.col_dot,
                             self._grad_views["som_layer.prototypes"], gx_out, accumulate_gx=accumulate)
+
+        def streams_now():
+            return [st for st in (main, self.vit._side) if st is not None]
 
         side = self._som_stream if self.vit._side is not None else None
         if self.classification or side is None:
@@ -1076,28 +1151,39 @@ class ViTSOM(_ArenaOwner, _Base):
                 ops.linear_bwd_input(a.dlogits, self.cls_head.weight, self._cls_view(a.d_xe, a), accumulate=True)
             else:
                 self.vit._decoder_bwd(a, Gv, self._WT)
+                if "decoder" in buckets:
+                    self._reduce_early(*buckets["decoder"], streams=streams_now())
             som_backward(gX, True)
-            self._start_prototype_allreduce()
+            if "som" in buckets:
+                self._reduce_early(*buckets["som"], streams=streams_now())
         else:
             # The SOM backward depends only on the forward (coef, X, W), so it runs on a stream of its
-            # own under the decoder backward; its input gradient goes to a buffer of its own and is added
-            # to the decoder's once both are done.  The prototype all-reduce is issued from that
-            # stream too: it starts the moment gW is final, before the decoder backward has finished.
-            if getattr(a, "d_som", None) is None or a.d_som.shape != gX.shape:
-                a.d_som = torch.empty(gX.shape, dtype=torch.float32, device=gX.device)
-            ev = torch.cuda.Event()
+            # own under the decoder backward and writes its input gradient straight into (the zeroed)
+            # d_xe; the decoder's last GEMM waits for it and accumulates on top.  The prototype
+            # all-reduce is issued behind it: it starts the moment gW is final, before the decoder
+            # backward has finished.
+            ev = self.vit._event()
             ev.record()
-            with torch.cuda.stream(side):
-                side.wait_event(ev)
-                som_backward(a.d_som, False)
-                self._start_prototype_allreduce()
-                som_done = side.record_event()
-            self.vit._decoder_bwd(a, Gv, self._WT)
-            torch.cuda.current_stream().wait_event(som_done)
-            gX.add_(a.d_som)
-        self.vit._encoder_bwd(a, Gv, self._WT)
+            side.wait_event(ev)
+            with on_stream(side):
+                ops.fill(a.d_xe, 0.0)
+                som_backward(gX, False)
+            if "som" in buckets:
+                self._reduce_early(*buckets["som"], streams=[side])
+            som_done = self.vit._event()
+            som_done.record(side)
+            self.vit._decoder_bwd(a, Gv, self._WT, before_dxe=lambda: main.wait_event(som_done))
+            if "decoder" in buckets:
+                self._reduce_early(*buckets["decoder"], streams=streams_now())
+
+        def on_block(i):
+            b = buckets.get(f"enc{i}")
+            if b is not None:
+                self._reduce_early(*b, streams=streams_now())
+
+        self.vit._encoder_bwd(a, Gv, self._WT, on_block if buckets else None)
         if self.vit._side is not None:
-            torch.cuda.current_stream().wait_stream(self.vit._side)     # every gradient is final from here on
+            main.wait_stream(self.vit._side)     # every gradient is final from here on
             self.vit.__dict__.setdefault("_side_pending", []).clear()
 
     # -- data-parallel exchange ----------------------------------------------------------------

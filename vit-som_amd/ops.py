@@ -354,6 +354,14 @@ def fill(t, value):
     return t
 
 
+def scale_by(t, scale_dev):
+    """t *= scale_dev[0] (device scalar, no host sync)."""
+    _f32(t, "t"); _f32(scale_dev, "scale")
+    assert t.is_contiguous() and scale_dev.numel() == 1
+    check(lib.vsom_scale_by(ptr(t), t.numel(), ptr(scale_dev), stream()), "vsom_scale_by")
+    return t
+
+
 def reduce_slabs(slabs, out):
     nslabs, n = slabs.shape
     check(lib.vsom_reduce_slabs(ptr(slabs), slabs.stride(0), nslabs, ptr(out), n, stream()), "vsom_reduce_slabs")
