@@ -1,5 +1,5 @@
 """RCCL sanity on the one-GPU box: a 1-rank "nccl" group, then the model's exchange code path
-(early async all-reduce of the prototype slice + the remaining pieces) with world_size forced to 2
+(bucketed early all-reduces from the comm stream + the remaining pieces) with world_size forced to 2
 so that the overlapped branch runs; a 1-rank sum is the identity, so the trajectory must equal the
 non-overlapped one bit for bit."""
 import os, sys, time, torch, torch.distributed as dist
@@ -27,7 +27,7 @@ def run(overlap, steps=6):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(steps):
         loss = m.train_step_fused(x, y)
-        used += m._early is not None
+        used += len(m._works)
         opt.step()
         losses.append(float(loss))
     torch.cuda.synchronize()
@@ -37,7 +37,7 @@ l0, u0, p0, t0 = run(False)
 l1, u1, p1, t1 = run(True)
 print("no overlap :", ["%.6f" % v for v in l0], "early pieces", u0, "%.2f ms/step" % (1e3 * t0))
 print("overlap    :", ["%.6f" % v for v in l1], "early pieces", u1, "%.2f ms/step" % (1e3 * t1))
-assert u0 == 0 and u1 == 6, (u0, u1)
+assert u0 == 0 and u1 >= 6 * 4, (u0, u1)
 assert l0 == l1 and torch.equal(p0, p1), "overlapped exchange changed the result"
 print("overlapped exchange: identical trajectory")
 dist.destroy_process_group()
