@@ -238,6 +238,20 @@ int vsom_contingency(const int64_t* a, const int64_t* b, long n, int na, int nb,
 /* out[r] = first argmax_c X[r,c] -- torch.argmax(cls_logits, dim=1), evaluation.py:119 */
 int vsom_argmax_rows(const float* X, long ldx, int rows, int cols, int64_t* out, vsom_stream_t stream);
 
+/* Cosine BMU pass as a reduced-precision contraction + exact re-rank; replaces
+   F.normalize x 2 + matmul + argmin of som_layer.py:119-122, 83-89 in one pass over X and W:
+   stage 1 = X W^T on the bf16 matrix cores from a two-piece round-to-nearest split (three products; |error of
+   the normalised dot| <= 3 * 2^-16) + the squared row norms of X and W; stage 2 = inv_nx / inv_nw
+   (1 / max(|row|, 1e-12)), dist, and bmu = first argmin after every prototype within 1e-4 of the approximate
+   minimum has been re-ranked with an exact (fp64-accumulated) dot product, whose distance also replaces the
+   approximate one in dist: bmu == argmin(dist) exactly.  K <= 2048; rows 16-byte aligned. */
+size_t vsom_bmu_cosine_x3_workspace_bytes(int B, int K, int L);
+int vsom_bmu_cosine_x3_dots(const float* X, long ldx, const float* W, int B, int K, int L, void* ws, size_t ws_bytes,
+                            vsom_stream_t stream);
+int vsom_bmu_cosine_x3_finalize(const float* X, long ldx, const float* W, const void* ws, size_t ws_bytes, float* dist,
+                                int64_t* bmu, float* inv_nx, float* inv_nw, int* reranked, int B, int K, int L,
+                                vsom_stream_t stream);
+
 /* ------------------------------------------------------------------ small utilities */
 int vsom_fill(float* p, long n, float value, vsom_stream_t stream);
 /* p[i] *= *scale_dev (a device scalar: no host sync) -- the incoming gradient of loss.backward(), applied to the

@@ -305,6 +305,65 @@ def test_bmu_cosine(ops, O, B, K, L):
     assert torch.equal(bmu, bmu2)
 
 
+@pytest.mark.parametrize("B,K,L", [(70, 15, 256), (64, 576, 3136), (128, 16, 12288), (33, 100, 48), (5, 7, 20), (512, 1600, 12288),
+                                    (130, 2048, 192)])
+def test_bmu_cosine_x3_rerank(ops, B, K, L):
+    """Reduced-precision contraction + exact re-rank: norms, distances (1e-5 abs vs fp64: the three-product error is
+    <= 4.6e-5 in the worst case, ~1e-7 observed), bmu == first argmin of the returned distances, and bmu equal to the
+    fp64 argmin outside the fp32 near-tie window -- the same policy as the exact-f32 pass."""
+    x = rnd(B, L, seed=1)
+    W = F.normalize(torch.rand(K, L, generator=torch.Generator().manual_seed(2)), dim=1)
+    d64 = 1 - F.normalize(x.double(), dim=1) @ F.normalize(W.double(), dim=1).T
+    xd, Wd = dev(x), dev(W)
+    inx, inw = torch.empty(B, device=DEV), torch.empty(K, device=DEV)
+    dist, bmu = torch.empty(B, K, device=DEV), torch.empty(B, dtype=torch.int64, device=DEV)
+    cnt = torch.zeros(1, dtype=torch.int32, device=DEV)
+    ops.bmu_cosine_x3_fwd(xd, Wd, dist, bmu, inx, inw, cnt)
+    assert torch.allclose(inx.cpu().double(), 1 / x.double().norm(dim=1), rtol=2e-6)
+    assert torch.allclose(inw.cpu().double(), 1 / W.double().norm(dim=1), rtol=2e-6)
+    err = float((dist.cpu().double() - d64).abs().max())
+    assert err < 1e-5, err
+    assert torch.equal(bmu.cpu(), dist.cpu().argmin(1))
+    ok, nmis = bmu_policy_ok(bmu.cpu(), d64)
+    srt = d64.sort(1).values
+    near = int(((srt[:, 1] - srt[:, 0]) <= 2e-6).sum()) if K > 1 else 0
+    print(f"bmu_x3 B={B} K={K} L={L}: max |dist - fp64| {err:.2e}, rows re-ranked {int(cnt)}, "
+          f"rows inside the 2e-6 near-tie window {near}, BMU != fp64 argmin on {nmis} rows")
+    assert ok, f"{nmis} BMU mismatches outside near-ties"
+    # deterministic, and identical without the distance output
+    bmu2 = torch.empty(B, dtype=torch.int64, device=DEV)
+    ops.bmu_cosine_x3_fwd(xd, Wd, None, bmu2, inx, inw)
+    assert torch.equal(bmu, bmu2)
+
+
+def test_bmu_cosine_x3_forced_rerank(ops):
+    """Prototypes closer to each other than the contraction's error bound: the approximate minimum is ambiguous, the
+    exact re-rank must pick the fp64 argmin (gaps of 3e-6 .. 3e-5 here, far outside fp32 noise), and exact ties the
+    lowest index."""
+    B, K, L = 16, 64, 1024
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, L, generator=g)
+    W = torch.rand(K, L, generator=g)
+    for i in range(B):                         # three near-copies of x_i at prototypes 3i+1 .. 3i+3, ever so slightly apart
+        for j, eps in enumerate((2e-3, 2.5e-3, 3e-3)):
+            W[3 * i + 1 + j] = x[i] + eps * torch.randn(L, generator=g)
+    W[0] = x[5]; W[63] = x[5]                  # exact tie for sample 5 (identical rows) -> lowest index 0
+    d64 = 1 - F.normalize(x.double(), dim=1) @ F.normalize(W.double(), dim=1).T
+    inx, inw = torch.empty(B, device=DEV), torch.empty(K, device=DEV)
+    dist, bmu = torch.empty(B, K, device=DEV), torch.empty(B, dtype=torch.int64, device=DEV)
+    cnt = torch.zeros(1, dtype=torch.int32, device=DEV)
+    ops.bmu_cosine_x3_fwd(dev(x), dev(W), dist, bmu, inx, inw, cnt)
+    assert int(cnt) == B                       # every row had several candidates inside the window
+    assert int(bmu[5]) == 0
+    ref = d64.argmin(1)
+    srt = d64.sort(1).values
+    gap = srt[:, 1] - srt[:, 0]
+    clear = gap > 2e-7                         # exact (fp64-accumulated) re-rank resolves gaps far below fp32 noise
+    assert torch.equal(bmu.cpu()[clear], ref[clear]), (bmu.cpu(), ref, gap)
+    assert torch.equal(bmu.cpu(), dist.cpu().argmin(1))
+    assert float((dist.cpu().double() - d64).abs().max()) < 1e-5
+
+
 def test_bmu_exact_ties_pick_lowest_index(ops):
     B, K, L = 8, 40, 64
     x = rnd(B, L, seed=1)

@@ -59,6 +59,10 @@ SIGNATURES = {
                                       C.c_size_t, c_stream]),
     "vsom_bmu_cosine_dots": (C.c_int, [c_fp, C.c_long, c_fp, C.c_int, C.c_int, C.c_int, c_fp, C.c_size_t, c_stream]),
     "vsom_bmu_cosine_finalize": (C.c_int, [c_fp, C.c_size_t, c_fp, c_fp, c_fp, c_fp, C.c_int, C.c_int, C.c_int, c_stream]),
+    "vsom_bmu_cosine_x3_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "vsom_bmu_cosine_x3_dots": (C.c_int, [c_fp, C.c_long, c_fp, C.c_int, C.c_int, C.c_int, c_fp, C.c_size_t, c_stream]),
+    "vsom_bmu_cosine_x3_finalize": (C.c_int, [c_fp, C.c_long, c_fp, c_fp, C.c_size_t, c_fp, c_fp, c_fp, c_fp, c_fp, C.c_int,
+                                              C.c_int, C.c_int, c_stream]),
     "vsom_som_neigh_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "vsom_som_neigh_loss": (C.c_int, [c_fp, c_fp, c_fp, C.c_float, c_fp, c_fp, C.c_float, c_fp, c_fp, c_fp, c_fp,
                                       c_fp, C.c_int, C.c_int, C.c_int, c_fp, C.c_size_t, c_stream]),

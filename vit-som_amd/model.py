@@ -544,6 +544,7 @@ class SOMLayer(_Base):
         s.device = device
         s.inx, s.inw = f(B), f(K)
         s.dist, s.bmu = f(B, K), torch.empty(B, dtype=torch.int64, device=device)
+        s.reranked = torch.zeros(1, dtype=torch.int32, device=device)      # rows whose BMU needed the exact re-rank (cumulative)
         s.coef, s.row_dot, s.col_dot = f(B, K), f(B), f(K)
         s.loss_sum = f(1)
         self._bufs = {B: s}
@@ -560,9 +561,15 @@ class SOMLayer(_Base):
 
     def _distances_into(self, x2d, s: _Acts):
         if self._dist_mode == ops.DIST_COSINE:
-            ops.row_inv_norm(x2d, s.inx)
-            ops.row_inv_norm(self.prototypes, s.inw)
-            ops.bmu_cosine_fwd(x2d, self.prototypes, s.inx, s.inw, s.dist, s.bmu)
+            W = self.prototypes
+            if (ops.get_gemm_mode() == ops.GEMM_SPLIT_BF16 and W.shape[0] <= 2048 and W.shape[1] % 4 == 0
+                    and x2d.stride(0) % 4 == 0 and x2d.data_ptr() % 16 == 0):
+                # norms + reduced-precision contraction + exact re-rank in one pass over X and W
+                ops.bmu_cosine_x3_fwd(x2d, W, s.dist, s.bmu, s.inx, s.inw, s.reranked)
+            else:
+                ops.row_inv_norm(x2d, s.inx)
+                ops.row_inv_norm(W, s.inw)
+                ops.bmu_cosine_fwd(x2d, W, s.inx, s.inw, s.dist, s.bmu)
         elif self._dist_mode == ops.DIST_MANHATTAN:
             ops.bmu_manhattan_fwd(x2d, self.prototypes, s.dist, s.bmu)
         else:                                   # euclidean: inx / inw hold the squared norms

@@ -281,6 +281,29 @@ def som_bwd_manhattan(x, W, coef, gW, gX, accumulate_gx=True):
                                      B, K, L, stream()), "vsom_som_bwd_manhattan")
 
 
+def bmu_cosine_x3_fwd(x, W, dist: Optional[torch.Tensor], bmu, inv_nx, inv_nw, reranked: Optional[torch.Tensor] = None):
+    """Cosine BMU pass (norms + three-product bf16 contraction + exact re-rank) -> dist, bmu, inv_nx, inv_nw.
+    `reranked`: optional int32 device scalar counting the rows whose minimum had to be re-ranked."""
+    B, L = x.shape
+    K = W.shape[0]
+    _f32(x, "x"); _f32(W, "W"); _f32(inv_nx, "inv_nx"); _f32(inv_nw, "inv_nw")
+    assert W.is_contiguous() and W.shape[1] == L and bmu.dtype == torch.int64 and (dist is None or dist.is_contiguous())
+    assert reranked is None or (reranked.dtype == torch.int32 and reranked.is_cuda)
+    nbytes = lib.vsom_bmu_cosine_x3_workspace_bytes(B, K, L)
+    ws = scratch(nbytes, x.device)
+    rec = _timers.get("bmu_cosine_dots")
+    if rec is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    check(lib.vsom_bmu_cosine_x3_dots(ptr(x), _rows(x), ptr(W), B, K, L, ptr(ws), ws.numel(), stream()), "vsom_bmu_cosine_x3_dots")
+    if rec is not None:
+        e1.record()
+        rec.append((e0, e1))
+    check(lib.vsom_bmu_cosine_x3_finalize(ptr(x), _rows(x), ptr(W), ptr(ws), ws.numel(), ptr(dist), ptr(bmu), ptr(inv_nx),
+                                          ptr(inv_nw), ptr(reranked), B, K, L, stream()), "vsom_bmu_cosine_x3_finalize")
+    return dist, bmu
+
+
 def bmu_cosine_fwd(x, W, inv_nx, inv_nw, dist: Optional[torch.Tensor], bmu):
     B, L = x.shape
     K = W.shape[0]
