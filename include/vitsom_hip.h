@@ -3,7 +3,7 @@
  * The reference (aluo7/ViT-SOM) is pure Python and has NO FFI/plugin interface;
  * each entry point below replaces the torch/ATen op sequence at the cited reference lines
  * (paths relative to the reference repo root).  A maintainer binds them with ctypes
- * (see INTEGRATION.md); the build's own host mirror lives in vit-som_amd/.
+ * (see INTEGRATION.md); the build's own host mirror lives in vit_som_amd/.
  *
  * Conventions (every entry):
  *   - returns 0 (VSOM_OK) on success, a negative VSOM_E* for a rejected call (bad shape,

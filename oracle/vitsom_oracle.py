@@ -3,7 +3,7 @@
 This file is a from-scratch CPU restatement (plain torch CPU ops, fp32 or fp64) of the
 arithmetic of the reference's hot path.  It is imported ONLY by ``tests/``,
 ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of ``bench.py``; the product
-package (``vit-som_amd/``) never imports it and has no CPU fallback.
+package (``vit_som_amd/``) never imports it and has no CPU fallback.
 
 Parity pin: the restatement is checked against outputs of the reference itself, produced in
 the build container by ``oracle/gen_golden.py`` (reference modules imported unmodified from

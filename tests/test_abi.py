@@ -53,7 +53,7 @@ def test_argument_validation_without_gpu():
 
 def test_no_oracle_import_in_product():
     """The product package must never route through the CPU oracle."""
-    pkg = os.path.join(ROOT, "vit-som_amd")
+    pkg = os.path.join(ROOT, "vit_som_amd")
     for dirpath, _, files in os.walk(pkg):
         for f in files:
             if f.endswith((".py", ".hip", ".h")):
