@@ -238,6 +238,14 @@ int vsom_contingency(const int64_t* a, const int64_t* b, long n, int na, int nb,
 /* out[r] = first argmax_c X[r,c] -- torch.argmax(cls_logits, dim=1), evaluation.py:119 */
 int vsom_argmax_rows(const float* X, long ldx, int rows, int cols, int64_t* out, vsom_stream_t stream);
 
+/* SOMLayer.som_loss(weights, distances) = mean(weights * distances) for ARBITRARY weights (som_layer.py:137-142):
+   loss_sum <- sum_ik weights[i,k] dist[i,k]; with coef/row_dot/col_dot given, also the backward coefficients of
+   grad_scale * that sum w.r.t. the distances' inputs (what vsom_som_bwd consumes) -- with weights = an upstream
+   gradient dL/d dist this is the autograd of SOMLayer.forward itself.  Workspace: vsom_som_neigh_workspace_bytes. */
+int vsom_som_weighted_loss(const float* dist, const float* weights, const float* inv_nx, const float* inv_nw,
+                           float grad_scale, float* loss_sum, float* coef, float* row_dot, float* col_dot, int B, int K,
+                           int distance, void* ws, size_t ws_bytes, vsom_stream_t stream);
+
 /* Cosine BMU pass as a reduced-precision contraction + exact re-rank; replaces
    F.normalize x 2 + matmul + argmin of som_layer.py:119-122, 83-89 in one pass over X and W:
    stage 1 = X W^T on the bf16 matrix cores from a two-piece round-to-nearest split (three products; |error of
@@ -254,6 +262,10 @@ int vsom_bmu_cosine_x3_finalize(const float* X, long ldx, const float* W, const 
 
 /* ------------------------------------------------------------------ small utilities */
 int vsom_fill(float* p, long n, float value, vsom_stream_t stream);
+/* out[i] = factor * (*scale_dev) * a[i] * b[i]  (b, scale_dev nullable -> 1): the elementwise products autograd needs
+   for mean(weights * distances) (som_layer.py:137-142) with the upstream gradient as a device scalar */
+int vsom_scaled_mul(float* out, const float* a, const float* b, long n, const float* scale_dev, float factor,
+                    vsom_stream_t stream);
 /* p[i] *= *scale_dev (a device scalar: no host sync) -- the incoming gradient of loss.backward(), applied to the
    loss-side gradient seeds before the backward kernels run (torch autograd's role at vit_som.py:80-105) */
 int vsom_scale_by(float* p, long n, const float* scale_dev, vsom_stream_t stream);

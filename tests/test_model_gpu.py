@@ -389,3 +389,69 @@ def test_bad_inputs_fail_loudly():
         m(torch.zeros(2, 3, 8, 8, device=DEV))                       # wrong channel count
     with pytest.raises(ValueError):
         m(torch.zeros(2, 1, 16, 16, device=DEV))                     # wrong image size
+
+
+@pytest.mark.parametrize("name", ["ref_cluster_tiny", "ref_hexa_euclid_tiny", "ref_manhattan_tiny"])
+def test_submodules_are_differentiable_on_their_own(name):
+    """A reference user composes model.vit(x) / model.som_layer(z) / som_loss(w, d) in a loss of their own (SURVEY 8(b):
+    every op differentiable on the torch side): gradients of such a composition against the CPU oracle under torch
+    autograd, with weights that are NOT the neighbourhood of the BMU (som_loss must honour its `weights` argument)."""
+    from oracle import vitsom_oracle as O
+    z, cfg = load_golden(name)
+    P = golden_params(z)
+    d = O.Dims(cfg)
+    x = torch.from_numpy(z["x"])
+    B, K = x.shape[0], P["som_layer.prototypes"].shape[0]
+    w_any = torch.rand(B, K, generator=torch.Generator().manual_seed(3)) + 0.1          # arbitrary positive weights
+
+    def compose(vit_fn, som_fn, loss_fn, xin, wts):
+        cls, patches, recon = vit_fn(xin)
+        dist, bmu = som_fn(patches.flatten(1))
+        return 0.7 * loss_fn(wts, dist) + 0.3 * (recon - xin).abs().mean() + 0.1 * cls.pow(2).mean() + 0.05 * patches.mean(), bmu
+
+    # oracle (CPU autograd)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in P.items() if k in O.trainable_keys(P)}
+    Pl = dict(P); Pl.update(leaves)
+    ref, bmu_ref = compose(lambda t: O.vit_forward(Pl, t, d), lambda t: O.som_forward(t, Pl["som_layer.prototypes"], d.distance_fcn),
+                           O.som_loss, x, w_any)
+    ref.backward()
+    # the build
+    m = build(cfg, P)
+    m.zero_grad(set_to_none=True)
+    out, bmu = compose(m.vit, m.som_layer, m.som_layer.som_loss, x.to(DEV), w_any.to(DEV))
+    out.backward()
+    assert abs(float(out) - float(ref)) < 2e-5
+    assert torch.equal(bmu.cpu(), bmu_ref)
+    worst = 0.0
+    for n, p in m.named_parameters():
+        if not p.requires_grad or n.startswith("cls_head"):
+            continue
+        assert p.grad is not None, n
+        worst = max(worst, rel_err(p.grad.cpu(), leaves[n].grad))
+    assert worst < 1e-4, worst
+    # som_loss on its own: value and both gradients for arbitrary weights
+    dd = torch.rand(B, K, generator=torch.Generator().manual_seed(4)).to(DEV).requires_grad_(True)
+    ww = w_any.to(DEV).clone().requires_grad_(True)
+    l = m.som_layer.som_loss(ww, dd)
+    l.backward()
+    assert abs(float(l) - float((w_any * dd.detach().cpu()).mean())) < 1e-6
+    assert torch.allclose(dd.grad.cpu(), w_any / (B * K), atol=1e-9) and torch.allclose(ww.grad, dd.detach() / (B * K), atol=1e-9)
+
+
+def test_optimizer_step_with_closure_runs_backward():
+    """Lightning's automatic optimization calls optimizer.step(closure) with a closure that runs training_step +
+    backward: the closure must execute with autograd enabled (torch.optim.AdamW does the same)."""
+    z, cfg = load_golden("ref_cluster_tiny")
+    m = build(cfg, golden_params(z))
+    m.set_schedule(int(z["n_train"]), int(z["est_steps"]))
+    (opt,), _ = m.configure_optimizers()
+    x, y = torch.from_numpy(z["x"]).to(DEV), torch.from_numpy(z["y"]).to(DEV)
+    before = m.arena.params.clone()
+
+    def closure():
+        loss = m.training_step((x, y), 0)
+        loss.backward()
+        return loss
+
+    loss = opt.step(closure)
+    assert loss is not None and torch.isfinite(loss) and not torch.equal(before, m.arena.params)

@@ -187,6 +187,14 @@ __global__ __launch_bounds__(256) void scale_by_kernel(float* __restrict__ p, lo
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) p[i] *= v;
 }
 
+// out[i] = factor * (*scale_dev) * a[i] * b[i]      (b nullable -> 1; scale_dev nullable -> 1)
+__global__ __launch_bounds__(256) void scaled_mul_kernel(float* __restrict__ out, const float* __restrict__ a,
+                                                         const float* __restrict__ b, long n, const float* __restrict__ s,
+                                                         float factor) {
+    const float v = (s ? *s : 1.0f) * factor;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) out[i] = v * a[i] * (b ? b[i] : 1.0f);
+}
+
 // batched 32x32-tile transpose through LDS; blockIdx.y = tensor, blockIdx.x = tile (surplus tiles exit)
 __global__ __launch_bounds__(256) void transpose_many_kernel(const float* __restrict__ src_base, float* __restrict__ dst_base,
                                                              const long long* __restrict__ table) {
@@ -241,6 +249,14 @@ int vsom_scale_by(float* p, long n, const float* scale_dev, vsom_stream_t stream
     if (n == 0) return VSOM_OK;
     hipLaunchKernelGGL(scale_by_kernel, dim3(grid_for(n, 1024, 4096)), dim3(256), 0, stream, p, n, scale_dev);
     VSOM_LAUNCH_CHECK("scale_by_kernel");
+}
+
+int vsom_scaled_mul(float* out, const float* a, const float* b, long n, const float* scale_dev, float factor,
+                    vsom_stream_t stream) {
+    VSOM_REQUIRE(out && a && n >= 0, VSOM_EINVAL, "scaled_mul: bad arguments");
+    if (n == 0) return VSOM_OK;
+    hipLaunchKernelGGL(scaled_mul_kernel, dim3(grid_for(n, 1024, 4096)), dim3(256), 0, stream, out, a, b, n, scale_dev, factor);
+    VSOM_LAUNCH_CHECK("scaled_mul_kernel");
 }
 
 int vsom_transpose_many(const float* src_base, float* dst_base, const long long* table, int count, int max_rows,

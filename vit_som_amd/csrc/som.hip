@@ -121,15 +121,23 @@ __global__ __launch_bounds__(256) void som_neigh_row_kernel(const float* __restr
                                                             const float* __restrict__ inv_nw, float c,
                                                             float* __restrict__ h_out, float* __restrict__ coef,
                                                             float* __restrict__ row_dot,
-                                                            float* __restrict__ loss_part, int K, int euclid) {
+                                                            float* __restrict__ loss_part, int K, int euclid,
+                                                            const float* __restrict__ h_in) {
+    // h_in != null: explicit weights h[i,k] = h_in[i,k] (any tensor; som_loss(weights, distances) and the autograd
+    // of the distances themselves) instead of the Gaussian neighbourhood of the BMU
     const int i = blockIdx.x;
-    const int64_t b = bmu[i];
-    const float by = grid[2 * b], bx = grid[2 * b + 1];
+    const int64_t b = h_in ? 0 : bmu[i];
+    const float by = h_in ? 0.f : grid[2 * b], bx = h_in ? 0.f : grid[2 * b + 1];
     const float rx = (inv_nx && !euclid) ? inv_nx[i] : 0.f;
     float lsum = 0.f, dsum = 0.f;
     for (int k = threadIdx.x; k < K; k += 256) {
-        const float dy = grid[2 * k] - by, dx = grid[2 * k + 1] - bx;
-        const float h = expf(-(dy * dy + dx * dx) * inv_2T2);
+        float h;
+        if (h_in) {
+            h = h_in[(long)i * K + k];
+        } else {
+            const float dy = grid[2 * k] - by, dx = grid[2 * k + 1] - bx;
+            h = expf(-(dy * dy + dx * dx) * inv_2T2);
+        }
         const float d = dist[(long)i * K + k];
         if (h_out) h_out[(long)i * K + k] = h;
         if (euclid == 2) {                                      // manhattan: dLoss/d dist = c h
@@ -161,17 +169,23 @@ __global__ __launch_bounds__(256) void som_neigh_col_kernel(const float* __restr
                                                             const int64_t* __restrict__ bmu,
                                                             const float* __restrict__ grid, float inv_2T2,
                                                             const float* __restrict__ inv_nw, float c,
-                                                            float* __restrict__ col_dot, int B, int K, int euclid) {
+                                                            float* __restrict__ col_dot, int B, int K, int euclid,
+                                                            const float* __restrict__ h_in) {
     __shared__ float part[8][32];
     const int cidx = threadIdx.x & 31, rg = threadIdx.x >> 5;
     const int k = blockIdx.x * 32 + cidx;
     float s0 = 0.f, s1 = 0.f;
     if (k < K) {
-        const float gy = grid[2 * k], gx = grid[2 * k + 1];
+        const float gy = h_in ? 0.f : grid[2 * k], gx = h_in ? 0.f : grid[2 * k + 1];
         auto term = [&](int i) {
-            const int64_t b = bmu[i];
-            const float dy = gy - grid[2 * b], dx = gx - grid[2 * b + 1];
-            const float h = expf(-(dy * dy + dx * dx) * inv_2T2);
+            float h;
+            if (h_in) {
+                h = h_in[(long)i * K + k];
+            } else {
+                const int64_t b = bmu[i];
+                const float dy = gy - grid[2 * b], dx = gx - grid[2 * b + 1];
+                h = expf(-(dy * dy + dx * dx) * inv_2T2);
+            }
             const float d = dist[(long)i * K + k];
             return euclid ? ((d > 0.f) ? h / d : 0.f) : h * (1.0f - d);
         };
@@ -310,14 +324,41 @@ int vsom_som_neigh_loss(const float* dist, const int64_t* bmu, const float* grid
     const float inv_2T2 = (float)(1.0 / (2.0 * (double)T * (double)T));
     float* part = static_cast<float*>(ws);
     hipLaunchKernelGGL(som_neigh_row_kernel, dim3(B), dim3(256), 0, stream, dist, bmu, grid, inv_2T2, inv_nx, inv_nw,
-                       grad_scale, h, coef, row_dot, part, K, euclid);
+                       grad_scale, h, coef, row_dot, part, K, euclid, (const float*)nullptr);
     int rc = hip_status(hipGetLastError(), "som_neigh_row_kernel");
     if (rc) return rc;
     rc = sum_partials(part, B, loss_sum, stream);
     if (rc) return rc;
     if (bwd && euclid != 2) {
         hipLaunchKernelGGL(som_neigh_col_kernel, dim3(cdiv(K, 32)), dim3(256), 0, stream, dist, bmu, grid, inv_2T2,
-                           inv_nw, grad_scale, col_dot, B, K, euclid);
+                           inv_nw, grad_scale, col_dot, B, K, euclid, (const float*)nullptr);
+        rc = hip_status(hipGetLastError(), "som_neigh_col_kernel");
+    }
+    return rc;
+}
+
+int vsom_som_weighted_loss(const float* dist, const float* weights, const float* inv_nx, const float* inv_nw,
+                           float grad_scale, float* loss_sum, float* coef, float* row_dot, float* col_dot, int B, int K,
+                           int distance, void* ws, size_t ws_bytes, vsom_stream_t stream) {
+    VSOM_REQUIRE(distance == VSOM_DIST_COSINE || distance == VSOM_DIST_EUCLIDEAN || distance == VSOM_DIST_MANHATTAN,
+                 VSOM_EUNSUPPORTED, "som_weighted_loss: distance %d not supported", distance);
+    const int euclid = distance == VSOM_DIST_EUCLIDEAN ? 1 : (distance == VSOM_DIST_MANHATTAN ? 2 : 0);
+    VSOM_REQUIRE(dist && weights && loss_sum, VSOM_EINVAL, "som_weighted_loss: null pointer");
+    VSOM_REQUIRE(B > 0 && K > 0, VSOM_EINVAL, "som_weighted_loss: bad shape");
+    VSOM_REQUIRE(ws && ws_bytes >= vsom_som_neigh_workspace_bytes(B, K), VSOM_EWORKSPACE, "som_weighted_loss: workspace too small");
+    const bool bwd = coef || row_dot || col_dot;
+    VSOM_REQUIRE(!bwd || (euclid == 2 && coef) || (coef && row_dot && col_dot && (euclid || (inv_nx && inv_nw))), VSOM_EINVAL,
+                 "som_weighted_loss: backward outputs need coef, row_dot, col_dot (and inv_nx, inv_nw for cosine) together");
+    float* part = static_cast<float*>(ws);
+    hipLaunchKernelGGL(som_neigh_row_kernel, dim3(B), dim3(256), 0, stream, dist, (const int64_t*)nullptr, (const float*)nullptr,
+                       0.f, inv_nx, inv_nw, grad_scale, (float*)nullptr, coef, row_dot, part, K, euclid, weights);
+    int rc = hip_status(hipGetLastError(), "som_neigh_row_kernel");
+    if (rc) return rc;
+    rc = sum_partials(part, B, loss_sum, stream);
+    if (rc) return rc;
+    if (bwd && euclid != 2) {
+        hipLaunchKernelGGL(som_neigh_col_kernel, dim3(cdiv(K, 32)), dim3(256), 0, stream, dist, (const int64_t*)nullptr,
+                           (const float*)nullptr, 0.f, inv_nw, grad_scale, col_dot, B, K, euclid, weights);
         rc = hip_status(hipGetLastError(), "som_neigh_col_kernel");
     }
     return rc;

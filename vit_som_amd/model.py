@@ -338,12 +338,21 @@ class ViTAutoencoder(nn.Module):
         xe = self._encode(x, a).view(a.B, a.N, self.embed_dim)
         return xe[:, 0].clone(), None
 
-    @torch.no_grad()
     def forward(self, x, return_attns=False):
-        """vit.py:202-240 -> (cls_token_out [B,E], patch_tokens_out [B,n,E], recon_img [B,C,S,S])."""
+        """vit.py:202-240 -> (cls_token_out [B,E], patch_tokens_out [B,n,E], recon_img [B,C,S,S]).  With autograd
+        enabled the three outputs are differentiable w.r.t. every trainable parameter (``_VitForwardFn``: the
+        stand-alone use of the sub-module; the fused training step of ViTSOM does not go through here)."""
         if return_attns:
             raise NotImplementedError("attention maps are never materialised by the fused kernels")
         x = self._check_input(x)
+        if torch.is_grad_enabled():
+            params = [p for _, p in _trainable_order(self)]
+            if any(p.requires_grad for p in params):
+                return _VitForwardFn.apply(x, self, *params)
+        with torch.no_grad():
+            return self._forward_impl(x)
+
+    def _forward_impl(self, x):
         a = self._buffers_for(x.shape[0], x.device)
         xe = self._encode(x, a).view(a.B, a.N, self.embed_dim)
         self._decode(a)
@@ -480,6 +489,107 @@ class ViTAutoencoder(nn.Module):
                             G("cls_token").view(E), a.B, self.in_chans, self.img_size, p, E)
 
 
+# ------------------------------------------------------------------------------------ per-module autograd
+class _VitForwardFn(torch.autograd.Function):
+    """ViTAutoencoder.forward for stand-alone use under autograd (models/vit.py:202-240): forward = the HIP forward
+    kernels; backward = the same HIP backward kernels the fused step uses, fed with the upstream gradients of
+    (cls, patches, recon).  The gradient w.r.t. the input image is not produced (nothing on the path needs it)."""
+
+    @staticmethod
+    def forward(ctx, x, vit, *params):
+        ctx.vit, ctx.B = vit, x.shape[0]
+        with torch.no_grad():
+            out = vit._forward_impl(x)
+        ctx.version = vit.__dict__["_fwd_version"] = vit.__dict__.get("_fwd_version", 0) + 1
+        return out
+
+    @staticmethod
+    def backward(ctx, g_cls, g_patches, g_recon):
+        vit = ctx.vit
+        if vit.__dict__.get("_fwd_version") != ctx.version:
+            raise RuntimeError("ViTAutoencoder: backward() after another forward() -- the activation buffers are reused "
+                               "per batch size; call backward before the next forward")
+        named = _trainable_order(vit)
+        with torch.no_grad():
+            a = vit._buffers_for(ctx.B, named[0][1].device)
+            grads = {n: torch.zeros_like(p) for n, p in named}
+            G = grads.__getitem__
+            E, N, B = vit.embed_dim, a.N, a.B
+            side, vit._side = vit._side, None                     # single stream: this is not the fused step
+            try:
+                if g_recon is not None:
+                    dp = a.dpred.view(B, N, -1)
+                    dp[:, 0].zero_()
+                    dp[:, 1:].copy_(vit.patchify(g_recon.float()))
+                    vit._decoder_bwd(a, G)
+                else:
+                    a.d_xe.zero_()
+                d = a.d_xe.view(B, N, E)
+                if g_cls is not None:
+                    d[:, 0].add_(g_cls)
+                if g_patches is not None:
+                    d[:, 1:].add_(g_patches)
+                vit._encoder_bwd(a, G)
+            finally:
+                vit._side = side
+        return (None, None) + tuple(grads[n] for n, _ in named)
+
+
+class _SomDistancesFn(torch.autograd.Function):
+    """SOMLayer.forward under autograd (som_layer.py:83-89, 111-125): distances differentiable w.r.t. the input rows
+    and the prototypes; the BMU indices are returned alongside (non-differentiable, argmin)."""
+
+    @staticmethod
+    def forward(ctx, x, W, layer):
+        with torch.no_grad():
+            s = layer._buffers_for(x.shape[0], x.device)
+            layer._distances_into(x, s)
+            dist, bmu = s.dist.clone(), s.bmu.clone()
+            ctx.save_for_backward(x, W, dist, s.inx.clone(), s.inw.clone())
+        ctx.mode = layer._dist_mode
+        ctx.mark_non_differentiable(bmu)
+        return dist, bmu
+
+    @staticmethod
+    def backward(ctx, g_dist, _g_bmu):
+        x, W, dist, inx, inw = ctx.saved_tensors
+        B, K = dist.shape
+        with torch.no_grad():
+            f = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dist.device)   # noqa: E731
+            coef, row_dot, col_dot, tmp = f(B, K), f(B), f(K), f(1)
+            # backward coefficients of sum(g * dist): the upstream gradient plays the role of the weights
+            ops.som_weighted_loss(dist, g_dist.float().contiguous(), tmp, inv_nx=inx, inv_nw=inw, grad_scale=1.0, coef=coef,
+                                  row_dot=row_dot, col_dot=col_dot, distance=ctx.mode)
+            gW, gX = torch.empty_like(W), torch.empty_like(x)
+            if ctx.mode == ops.DIST_MANHATTAN:
+                ops.som_bwd_manhattan(x, W, coef, gW, gX, accumulate_gx=False)
+            else:
+                ops.som_bwd(x, W, coef, row_dot, col_dot, gW, gX, accumulate_gx=False)
+        return gX, gW, None
+
+
+class _SomLossFn(torch.autograd.Function):
+    """mean(weights * distances) (som_layer.py:137-142) with gradients to both arguments."""
+
+    @staticmethod
+    def forward(ctx, weights, distances):
+        ctx.save_for_backward(weights, distances)
+        tmp = torch.empty(1, dtype=torch.float32, device=distances.device)
+        ops.som_weighted_loss(distances, weights, tmp)
+        out = torch.empty((), dtype=torch.float32, device=distances.device)
+        ops.scaled_mul(out.view(1), tmp, factor=1.0 / distances.numel())
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        weights, distances = ctx.saved_tensors
+        g = gout.detach().reshape(1).float().contiguous()
+        inv = 1.0 / distances.numel()
+        gw = ops.scaled_mul(torch.empty_like(weights), distances, scale_dev=g, factor=inv) if ctx.needs_input_grad[0] else None
+        gd = ops.scaled_mul(torch.empty_like(distances), weights, scale_dev=g, factor=inv) if ctx.needs_input_grad[1] else None
+        return gw, gd
+
+
 # ------------------------------------------------------------------------------------ SOM layer
 class SOMLayer(_Base):
     """models/som_layer.py:8-152 on the HIP kernels (cosine / euclidean / manhattan distance; square /
@@ -577,16 +687,20 @@ class SOMLayer(_Base):
             ops.row_sqnorm(self.prototypes, s.inw)
             ops.bmu_euclid_fwd(x2d, self.prototypes, s.inx, s.inw, s.dist, s.bmu)
 
-    @torch.no_grad()
     def forward(self, x):                                              # som_layer.py:83-89
+        """-> (distances [B,K], bmu_indices [B] int64).  With autograd enabled the distances are differentiable
+        w.r.t. `x` and the prototypes (``_SomDistancesFn``); the fused training step does not go through here."""
         if x.dim() > 2:
             x = x.flatten(start_dim=1)
         x = x.float()
         if x.stride(-1) != 1:
             x = x.contiguous()
-        s = self._buffers_for(x.shape[0], x.device)
-        self._distances_into(x, s)
-        return s.dist.clone(), s.bmu.clone()
+        if torch.is_grad_enabled() and (x.requires_grad or self.prototypes.requires_grad):
+            return _SomDistancesFn.apply(x, self.prototypes, self)
+        with torch.no_grad():
+            s = self._buffers_for(x.shape[0], x.device)
+            self._distances_into(x, s)
+            return s.dist.clone(), s.bmu.clone()
 
     def total_iterations(self) -> float:
         n = self._n_train
@@ -618,16 +732,11 @@ class SOMLayer(_Base):
                            distance=self._dist_mode)
         return h
 
-    @torch.no_grad()
     def som_loss(self, weights, distances):                            # som_layer.py:137-142
-        """mean(h * d).  Given the weights of compute_weights this is recomputed from (bmu, T) in
-        one fused pass; arbitrary `weights` tensors are not supported on the accelerated path."""
-        B, K = distances.shape
-        bmu = torch.argmax(weights, dim=1)        # h_ik is maximal (== 1) exactly at k = bmu(i)  [index plumbing]
-        tmp = torch.empty(1, dtype=torch.float32, device=distances.device)
-        ops.som_neigh_loss(distances.contiguous(), bmu, self.grid_positions, float(self.current_temperature), tmp,
-                           distance=self._dist_mode)
-        return tmp[0] / (B * K)
+        """mean(weights * distances) for ANY weights tensor, differentiable in both arguments."""
+        if weights.shape != distances.shape:
+            raise ValueError(f"som_loss: weights {tuple(weights.shape)} and distances {tuple(distances.shape)} differ")
+        return _SomLossFn.apply(weights.float().contiguous(), distances.float().contiguous())
 
 
 # ------------------------------------------------------------------------------------ optimiser
@@ -989,11 +1098,10 @@ class ViTSOM(_ArenaOwner, _Base):
         return self.config["hyperparameters"]["gamma"] * min(1.0, self._it / ramp_up_end_step)
 
     def _log(self, *a, **k):
+        """self.log / self.log_dict when a Lightning trainer is attached (vit_som.py:95-101); a no-op otherwise.
+        Errors raised by Lightning's logger propagate."""
         if _HAVE_PL and getattr(self, "_trainer", None) is not None:
-            try:
-                self.log_dict(*a, **k) if isinstance(a[0], dict) else self.log(*a, **k)
-            except Exception:
-                pass
+            self.log_dict(*a, **k) if isinstance(a[0], dict) else self.log(*a, **k)
 
     # -- fused forward + losses ---------------------------------------------------------------
     def _som_input(self, a: _Acts):

@@ -377,6 +377,28 @@ def fill(t, value):
     return t
 
 
+def scaled_mul(out, a, b=None, scale_dev=None, factor=1.0):
+    """out = factor * scale_dev[0] * a * b  (b / scale_dev optional)."""
+    _f32(out, "out"); _f32(a, "a")
+    assert out.is_contiguous() and a.is_contiguous() and out.numel() == a.numel() and (b is None or (b.is_contiguous() and b.numel() == a.numel()))
+    check(lib.vsom_scaled_mul(ptr(out), ptr(a), ptr(b), a.numel(), ptr(scale_dev), float(factor), stream()), "vsom_scaled_mul")
+    return out
+
+
+def som_weighted_loss(dist, weights, loss_sum, inv_nx=None, inv_nw=None, grad_scale=0.0, coef=None, row_dot=None, col_dot=None,
+                      distance=0):
+    """loss_sum <- sum(weights * dist) (+ backward coefficients of grad_scale * that sum when coef etc. are given)."""
+    B, K = dist.shape
+    _f32(dist, "dist"); _f32(weights, "weights")
+    assert dist.is_contiguous() and weights.is_contiguous() and weights.shape == dist.shape
+    nbytes = lib.vsom_som_neigh_workspace_bytes(B, K)
+    ws = scratch(nbytes, dist.device)
+    check(lib.vsom_som_weighted_loss(ptr(dist), ptr(weights), ptr(inv_nx), ptr(inv_nw), float(grad_scale), ptr(loss_sum), ptr(coef),
+                                     ptr(row_dot), ptr(col_dot), B, K, int(distance), ptr(ws), ws.numel(), stream()),
+          "vsom_som_weighted_loss")
+    return loss_sum
+
+
 def scale_by(t, scale_dev):
     """t *= scale_dev[0] (device scalar, no host sync)."""
     _f32(t, "t"); _f32(scale_dev, "scale")
