@@ -98,6 +98,14 @@ def test_evaluate_clustering_and_classification_against_oracle():
     P_, R_, F_, _ = precision_recall_fscore_support(ys, lg, average="macro", zero_division=np.nan)
     assert abs(acc - accuracy_score(ys, lg)) < 1e-12 and abs(p - P_) < 1e-12 and abs(r - R_) < 1e-12 and abs(f1 - F_) < 1e-12
     assert abs(calculate_purity(ys, bm) - purity) < 1e-12
+    # clustering configs carry num_classes == 0 and loaders may be label-sorted: the first batch then lacks the
+    # largest label and the table has to grow (the reference accepts arbitrary labels)
+    cfg0 = copy.deepcopy(cfg); cfg0["data"]["num_classes"] = 0
+    order = np.argsort(ys, kind="stable")
+    xs_all = torch.cat([x for x, _ in batches])[order]
+    sorted_batches = _Loader((xs_all[i:i + 7], torch.from_numpy(ys[order][i:i + 7])) for i in range(0, len(ys), 7))
+    p_sorted, n_sorted, _ = evaluate_clustering(m, cfg0, sorted_batches)
+    assert abs(p_sorted - purity) < 1e-12 and abs(n_sorted - nmi) < 1e-10
     # fast path == full forward
     x0 = batches[0][0].cuda()
     bmu_fast, logits_fast = m.predict(x0)

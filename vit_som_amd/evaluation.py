@@ -23,6 +23,13 @@ class _Table:
     def add(self, a, b):
         ops.contingency(a.contiguous().view(-1), b.contiguous().view(-1).long(), self.table, self.bad)
 
+    def grow_columns(self, nb):
+        """Widen the table to `nb` columns (labels are not known in advance for the clustering configs)."""
+        if nb > self.table.shape[1]:
+            t = torch.zeros(self.table.shape[0], nb, dtype=torch.int64, device=self.table.device)
+            t[:, :self.table.shape[1]] = self.table
+            self.table = t
+
     def numpy(self):
         if int(self.bad.item()):
             raise ValueError(f"{int(self.bad.item())} label/prediction values fell outside the contingency table")
@@ -94,12 +101,14 @@ def evaluate_clustering(model, config, dataloader, num_labels=None):
     for x, y in dataloader:
         x = x.to(dev, non_blocking=True).reshape(-1, C, S, S)
         y = y.to(dev, non_blocking=True)
+        if y.numel() and int(y.min()) < 0:
+            raise ValueError("evaluate_clustering: negative label in this batch")
+        L = int(num_labels) if num_labels else max(int(d.get("num_classes", 0)), int(y.max()) + 1 if y.numel() else 1, 1)
         if table is None:
-            L = int(num_labels) if num_labels else max(int(d.get("num_classes", 0)), int(y.max()) + 1, 1)
-            table = _Table(K, max(L, 1), dev)
+            table = _Table(K, L, dev)
+        elif not num_labels:
+            table.grow_columns(L)              # a later batch may carry a larger label than any seen so far
         bmu, _ = model.predict(x)
-        if int(table.table.shape[1]) <= 0:
-            raise ValueError("no labels")
         table.add(bmu, y.view(-1))
     w = table.numpy()
     purity, nmi = purity_from_table(w), nmi_from_table(w)

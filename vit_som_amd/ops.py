@@ -11,6 +11,7 @@ import torch
 from ._lib import check, lib, ptr, stream
 
 _scratch = {}
+_retired = []
 
 # Optional per-op HIP-event timing (bench.py): name -> list of (start_event, end_event) recorded
 # on torch's current stream, which is the stream every kernel here is launched on.
@@ -45,6 +46,11 @@ def scratch(nbytes: int, device) -> torch.Tensor:
     key = (torch.device(device).index or 0, stream() if torch.device(device).type == "cuda" else 0)
     buf = _scratch.get(key)
     if buf is None or buf.numel() < nbytes:
+        if buf is not None:
+            # The old block may still be read by kernels queued on a side stream the caching allocator knows nothing
+            # about (launches go to raw stream handles): never hand it back while the process lives (grow-only, a few
+            # blocks per stream at most).
+            _retired.append(buf)
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
         _scratch[key] = buf
     return buf

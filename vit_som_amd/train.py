@@ -111,6 +111,12 @@ def fit(model, config, train_loader, val_loader, ckpt_dir, dataset_name, use_val
                 x, y = x.to(dev), y.to(dev)
                 vloss, vb = vloss + model.validation_step((x, y), vb), vb + 1
                 correct, seen = correct + model._last["acc"] * x.shape[0], seen + x.shape[0]
+            if model.world_size > 1:                                     # every rank saw 1 / world of the validation set
+                agg = torch.stack([torch.as_tensor(correct, dtype=torch.float32, device=dev).reshape(()),
+                                   torch.tensor(float(seen), device=dev), torch.as_tensor(vloss, dtype=torch.float32, device=dev).reshape(()),
+                                   torch.tensor(float(vb), device=dev)])
+                torch.distributed.all_reduce(agg)
+                correct, seen, vloss, vb = agg[0], float(agg[1]), agg[2], float(agg[3])
             rec["val/accuracy"] = float(correct / max(seen, 1))
             rec["val/total_loss"] = float(vloss / max(vb, 1))
             if model.rank == 0 and rec["val/accuracy"] > best_acc:        # ModelCheckpoint(monitor='val/accuracy', mode='max')
@@ -146,6 +152,7 @@ def main(config, n_runs=5, max_epochs=None, make_loaders=synthetic_loaders, mode
         train_loader, val_loader, test_loader = make_loaders(config, rank, world)
         model = ViTSOM(copy.deepcopy(config))
         model.set_distributed(world, rank)
+        model.broadcast_parameters()                                      # DDP broadcasts rank 0's weights at construction
         out = fit(model, config, train_loader, val_loader, model_states_dir, dataset_name, use_validation, max_epochs, log)
         torch.cuda.synchronize()
         run_duration = time.time() - start
