@@ -195,6 +195,11 @@ __global__ __launch_bounds__(256) void scaled_mul_kernel(float* __restrict__ out
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) out[i] = v * a[i] * (b ? b[i] : 1.0f);
 }
 
+// out[0] = ca * a[0] + cb * b[0]   (total loss from the two loss sums; one lane)
+__global__ void lincomb2_kernel(float* __restrict__ out, const float* __restrict__ a, float ca, const float* __restrict__ b, float cb) {
+    if (threadIdx.x == 0) out[0] = fmaf(cb, b[0], ca * a[0]);
+}
+
 // batched 32x32-tile transpose through LDS; blockIdx.y = tensor, blockIdx.x = tile (surplus tiles exit)
 __global__ __launch_bounds__(256) void transpose_many_kernel(const float* __restrict__ src_base, float* __restrict__ dst_base,
                                                              const long long* __restrict__ table) {
@@ -257,6 +262,12 @@ int vsom_scaled_mul(float* out, const float* a, const float* b, long n, const fl
     if (n == 0) return VSOM_OK;
     hipLaunchKernelGGL(scaled_mul_kernel, dim3(grid_for(n, 1024, 4096)), dim3(256), 0, stream, out, a, b, n, scale_dev, factor);
     VSOM_LAUNCH_CHECK("scaled_mul_kernel");
+}
+
+int vsom_lincomb2(float* out, const float* a, float ca, const float* b, float cb, vsom_stream_t stream) {
+    VSOM_REQUIRE(out && a && b, VSOM_EINVAL, "lincomb2: null pointer");
+    hipLaunchKernelGGL(lincomb2_kernel, dim3(1), dim3(64), 0, stream, out, a, ca, b, cb);
+    VSOM_LAUNCH_CHECK("lincomb2_kernel");
 }
 
 int vsom_transpose_many(const float* src_base, float* dst_base, const long long* table, int count, int max_rows,

@@ -135,6 +135,20 @@ class _Acts:
     pass
 
 
+class _LossParts(dict):
+    """The step's loss terms for logging: 'total' is the tensor the step computed; 'main' (reconstruction or
+    cross-entropy) and 'som' are formed from the device-side sums only when somebody asks for them."""
+
+    def __init__(self, main_sum, main_scale, som_sum, som_scale, total, gamma_t, T):
+        super().__init__(total=total, gamma_t=gamma_t, T=T)
+        self._lazy = {"main": (main_sum, main_scale), "som": (som_sum, som_scale)}
+
+    def __missing__(self, key):
+        buf, scale = self._lazy[key]
+        self[key] = buf[0] * scale
+        return self[key]
+
+
 # ------------------------------------------------------------------------------------ ViT autoencoder
 class ViTAutoencoder(nn.Module):
     """MAE-style unmasked ViT autoencoder (models/vit.py:66-240); compute on the HIP kernels."""
@@ -288,19 +302,18 @@ class ViTAutoencoder(nn.Module):
             ev = self._event()
             ev.record()
             side.wait_event(ev)
-            # Only the first half of the blocks: the denser the forward runs, the lower the clock the power
-            # management leaves for the kernels right after it -- the f32-MFMA BMU pass took 168 / 175 / 185 /
-            # 189 us with 0 / 6 / 10 / 12 of 12 blocks split (step 12.10 / 11.93 / 11.85 / 11.81 ms); half keeps
-            # most of the gain and most of the BMU pass's speed.
-            nsplit = int(os.environ.get("VSOM_FWD_SPLIT_BLOCKS", str(len(self.blocks) // 2)))
+            # All blocks by default (A/B in one process, round 2: 0 / 6 / 12 of 12 blocks split -> 11.77 / 11.81 /
+            # 11.68 ms per step; round 1 kept it to half because the f32-MFMA BMU pass ran slower right after a dense
+            # forward -- the bf16 BMU pass does not).
+            nsplit = int(os.environ.get("VSOM_FWD_SPLIT_BLOCKS", str(len(self.blocks))))
             nsplit = max(0, min(nsplit, len(self.blocks)))
-            c = a.tok0[:Th]
-            for blk, L in zip(self.blocks[:nsplit], cuts[0][:nsplit]):
-                c = self._block_fwd(blk, L, c, Bh, a.N)
-            c = a.tok0[Th:]
-            with on_stream(side):
-                for blk, L in zip(self.blocks[:nsplit], cuts[1][:nsplit]):
-                    c = self._block_fwd(blk, L, c, Bh, a.N)
+            # enqueue the two chains alternately, block by block: the host feeds both streams at the same pace (all
+            # of chain 0 first left the second stream idle for the ~0.7 ms the host needs to enqueue six blocks)
+            c0, c1 = a.tok0[:Th], a.tok0[Th:]
+            for i in range(nsplit):
+                c0 = self._block_fwd(self.blocks[i], cuts[0][i], c0, Bh, a.N)
+                with on_stream(side):
+                    c1 = self._block_fwd(self.blocks[i], cuts[1][i], c1, Bh, a.N)
             ev2 = self._event()
             ev2.record(side)
             torch.cuda.current_stream().wait_event(ev2)
@@ -1163,6 +1176,7 @@ class ViTSOM(_ArenaOwner, _Base):
         dev = x.device
         if not hasattr(a, "main_sum"):
             a.main_sum = torch.empty(1, dtype=torch.float32, device=dev)
+            a.total = torch.empty(1, dtype=torch.float32, device=dev)
         c = gamma_t / (B * K)
         if want_grad:
             ops.som_neigh_loss(s.dist, s.bmu, self.som_layer.grid_positions, T, s.loss_sum, inv_nx=s.inx, inv_nw=s.inw,
@@ -1177,15 +1191,15 @@ class ViTSOM(_ArenaOwner, _Base):
                 yv = yv.long()
             ops.cross_entropy_ls(a.logits, yv.contiguous(), self.smoothing, a.main_sum,
                                  dlogits=a.dlogits if want_grad else None, grad_scale=1.0 / B)
-            main = a.main_sum[0] / B
+            main_scale = 1.0 / B
         else:
             ops.l1_unpatchify(a.pred, x, a.main_sum, dpred=a.dpred if want_grad else None, grad_scale=1.0 / x.numel(),
                               p=self.vit.patch_embed.patch_size[0])
-            main = a.main_sum[0] / x.numel()
-        som = s.loss_sum[0] / (B * K)
-        total = main + gamma_t * som
-        self._last = {"main": main, "som": som, "total": total, "gamma_t": gamma_t, "T": T}
-        return total
+            main_scale = 1.0 / x.numel()
+        # total = main + gamma_t * som from the two device-side sums, in one tiny kernel (no ATen arithmetic in the step)
+        ops.lincomb2(a.total, a.main_sum, main_scale, s.loss_sum, gamma_t / (B * K))
+        self._last = _LossParts(a.main_sum, main_scale, s.loss_sum, 1.0 / (B * K), a.total[0], gamma_t, T)
+        return a.total[0]
 
     def _ensure_streams(self, device):
         """The two extra HIP streams of the step (kept to two: a process has few hardware queues)."""

@@ -405,6 +405,12 @@ def som_weighted_loss(dist, weights, loss_sum, inv_nx=None, inv_nw=None, grad_sc
     return loss_sum
 
 
+def lincomb2(out, a, ca, b, cb):
+    """out[0] = ca * a[0] + cb * b[0] (device scalars)."""
+    check(lib.vsom_lincomb2(ptr(out), ptr(a), float(ca), ptr(b), float(cb), stream()), "vsom_lincomb2")
+    return out
+
+
 def scale_by(t, scale_dev):
     """t *= scale_dev[0] (device scalar, no host sync)."""
     _f32(t, "t"); _f32(scale_dev, "scale")
