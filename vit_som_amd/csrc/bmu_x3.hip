@@ -64,7 +64,7 @@ __device__ __forceinline__ void x3_load(X3Stage<ROWS, NT>& s, __amdgpu_buffer_rs
     for (int p = 0; p < ROWS / (NT / 8); ++p) s.v[p] = bload4(rsrc, (kok && o.off[p] != OOB) ? o.off[p] + kbytes : OOB);
 }
 
-// tile (WAVES_M WM 32) x (WAVES_N WN 32) x 32; LDS: 2 planes x (BM + BN) rows x 80 B.  The split costs ~18 VALU per
+// tile (WAVES_M WM 32) x (WAVES_N WN 32) x 32; LDS: 2 planes x (BM + BN) rows x 64 B (swizzled image of gemm_x6.h).  The split costs ~18 VALU per
 // float4 against 3 (not 6) MFMAs per 16-deep step, so the tile has to be LARGE to keep the loop off the VALU issue
 // limit: 7.5 VALU per MFMA at 128 x 128 (measured 89 us, issue-bound), 3.5 at 256 x 192.
 template <int WM, int WN, int WAVES_M, int WAVES_N>
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void bmu_x3_kernel(const Bm
             if (want_x) ssa[p] += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
             uint2 p1, p2;
             x3_split(v, p1, p2);
-            char* dst = As + (p * RPP + (t >> 3)) * X6_RS + ((t & 7) << 3);
+            char* dst = As + x6_piece_off(p * RPP + (t >> 3), t & 7);
             *reinterpret_cast<uint2*>(dst) = p1;
             *reinterpret_cast<uint2*>(dst + PA) = p2;
         }
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void bmu_x3_kernel(const Bm
             if (want_w) ssb[p] += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
             uint2 p1, p2;
             x3_split(v, p1, p2);
-            char* dst = Bs + (p * RPP + (t >> 3)) * X6_RS + ((t & 7) << 3);
+            char* dst = Bs + x6_piece_off(p * RPP + (t >> 3), t & 7);
             *reinterpret_cast<uint2*>(dst) = p1;
             *reinterpret_cast<uint2*>(dst + PB) = p2;
         }
@@ -142,12 +142,12 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void bmu_x3_kernel(const Bm
             for (int i = 0; i < WM; ++i)
 #pragma unroll
                 for (int pl = 0; pl < 2; ++pl)
-                    a[i][pl] = *reinterpret_cast<const bf16x8*>(As + pl * PA + (wm0 + i * 32 + r) * X6_RS + ks * 32 + h * 16);
+                    a[i][pl] = *reinterpret_cast<const bf16x8*>(As + pl * PA + x6_chunk_off(wm0 + i * 32 + r, 2 * ks + h));
 #pragma unroll
             for (int j = 0; j < WN; ++j)
 #pragma unroll
                 for (int pl = 0; pl < 2; ++pl)
-                    b[j][pl] = *reinterpret_cast<const bf16x8*>(Bs + pl * PB + (wn0 + j * 32 + r) * X6_RS + ks * 32 + h * 16);
+                    b[j][pl] = *reinterpret_cast<const bf16x8*>(Bs + pl * PB + x6_chunk_off(wn0 + j * 32 + r, 2 * ks + h));
 #pragma unroll
             for (int i = 0; i < WM; ++i)
 #pragma unroll

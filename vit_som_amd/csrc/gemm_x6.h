@@ -19,8 +19,8 @@
 // k-contiguous bf16 planes, so the MFMA loop is shared.
 // Tiles 128 x 64 x 32 (4 waves of 32 x 64) or 64 x 64 x 32 (2 x 2 waves of 32 x 32), register-staged like
 // gemm_f32.h; the split happens between the global load and the LDS store (4 and / 4 sub / 3
-// perm per pair of elements).  LDS holds three bf16 planes per operand, rows of 32 bf16 + 16 B
-// pad (80 B: conflict-free ds_read_b128 of 8 consecutive k).  Fragment layout of the 32x32x16
+// perm per pair of elements).  LDS holds three bf16 planes per operand, rows of 32 bf16 (64 B) with an
+// XOR chunk swizzle (x6_chunk_off: conflict-free reads AND stores).  Fragment layout of the 32x32x16
 // MFMA: lane (r = l & 31, h = l >> 5) supplies A[row r][k = 8h + j] and B[k = 8h + j][col r],
 // j = 0..7 -- one 16-byte LDS read per plane per 16-k step; the accumulator layout equals the
 // fp32 MFMA's, so the epilogues are shared.
@@ -48,7 +48,16 @@ __device__ __forceinline__ void x6_split(f32x4 v, uint2& p1, uint2& p2, uint2& p
     p3.x = __builtin_amdgcn_perm(x6_bits(s[1]), x6_bits(s[0]), SEL); p3.y = __builtin_amdgcn_perm(x6_bits(s[3]), x6_bits(s[2]), SEL);
 }
 
-constexpr int X6_RS = 80;        // bytes per plane row
+// LDS plane image: [row][64 B] = 32 bf16 of one k-tile, no padding; the 16-byte chunk c (8 consecutive k) of row R sits
+// at chunk position c ^ ((R >> 2) & 3).  With that XOR both access patterns are bank-conflict-free: the fragment reads
+// (ds_read_b128, lane = row: its 16-lane groups hit 16 different 16-byte slots of the 256-byte bank row) AND the staging
+// stores (ds_write_b64, 8 lanes per row: a 16-lane group covers two whole rows = 128 contiguous bytes).  The padded
+// [row][80 B] image of round 1 was conflict-free for the reads only -- every store was 2-way (SQ_LDS_BANK_CONFLICT = a
+// third of the LDS cycles of the kernel).
+constexpr int X6_RS = 64;        // bytes per plane row
+__device__ __forceinline__ int x6_chunk_off(int row, int chunk) { return row * X6_RS + ((chunk ^ ((row >> 2) & 3)) << 4); }
+// byte offset of the 8-byte piece kq (4 consecutive k, kq = 0..7) of row `row`
+__device__ __forceinline__ int x6_piece_off(int row, int kq) { return x6_chunk_off(row, kq >> 1) + ((kq & 1) << 3); }
 
 template <int ROWS>
 __device__ __forceinline__ void x6_store(const StageRegs<ROWS>& s, char* planes, int t) {
@@ -57,7 +66,7 @@ __device__ __forceinline__ void x6_store(const StageRegs<ROWS>& s, char* planes,
     for (int p = 0; p < ROWS / 32; ++p) {
         uint2 p1, p2, p3;
         x6_split(s.v[p], p1, p2, p3);
-        char* dst = planes + (p * 32 + (t >> 3)) * X6_RS + ((t & 7) << 3);
+        char* dst = planes + x6_piece_off(p * 32 + (t >> 3), t & 7);
         *reinterpret_cast<uint2*>(dst) = p1;
         *reinterpret_cast<uint2*>(dst + PL) = p2;
         *reinterpret_cast<uint2*>(dst + 2 * PL) = p3;
@@ -83,7 +92,7 @@ __device__ __forceinline__ void x6_store_ks(const X6Blk& b, char* planes, int pl
         const f32x4 col = {b.v[0][e], b.v[1][e], b.v[2][e], b.v[3][e]};      // 4 consecutive k of column 4mq+e
         uint2 p1, p2, p3;
         x6_split(col, p1, p2, p3);
-        char* dst = planes + (4 * mq + e) * X6_RS + (kg << 3);
+        char* dst = planes + x6_piece_off(4 * mq + e, kg);
         *reinterpret_cast<uint2*>(dst) = p1;
         *reinterpret_cast<uint2*>(dst + plane_bytes) = p2;
         *reinterpret_cast<uint2*>(dst + 2 * plane_bytes) = p3;
@@ -183,12 +192,12 @@ __global__ __launch_bounds__(256) void gemm_x6_kernel(const GemmP g) {
             for (int i = 0; i < WM; ++i)
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl)
-                    a[i][pl] = *reinterpret_cast<const bf16x8*>(As + pl * PA + (wm0 + i * 32 + r) * X6_RS + ks * 32 + h * 16);
+                    a[i][pl] = *reinterpret_cast<const bf16x8*>(As + pl * PA + x6_chunk_off(wm0 + i * 32 + r, 2 * ks + h));
 #pragma unroll
             for (int j = 0; j < WN; ++j)
 #pragma unroll
                 for (int pl = 0; pl < 3; ++pl)
-                    b[j][pl] = *reinterpret_cast<const bf16x8*>(Bs + pl * PB + (wn0 + j * 32 + r) * X6_RS + ks * 32 + h * 16);
+                    b[j][pl] = *reinterpret_cast<const bf16x8*>(Bs + pl * PB + x6_chunk_off(wn0 + j * 32 + r, 2 * ks + h));
 #pragma unroll
             for (int i = 0; i < WM; ++i)
 #pragma unroll
