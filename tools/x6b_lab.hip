@@ -12,6 +12,7 @@
 #include <vector>
 #include <cstring>
 #include <cmath>
+#include <algorithm>
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -377,9 +378,12 @@ void runp(float* C, int M, int N, int K, const unsigned short* Ap, const unsigne
 // MFMA fragments of stage g+1 read from LDS while the MFMAs of stage g run (register double buffer), counted
 // vmcnt.  Planes in layout i16 for both operands; K % 96 == 0 (the stage loop is unrolled by 6 = lcm(2 register
 // sets, 3 slots)).  Plain epilogue (ABL bit 0 skips it).
+__device__ unsigned long long* g_stamps = nullptr;      // [grid][4]: memtime start/end, memrealtime start/end (diagnostic build: ABL bit 3)
 template <int WM, int WN, int WAVES_M, int WAVES_N, int ABL>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void kq(float* __restrict__ C, int M, int N, int K,
                                                               const unsigned short* __restrict__ Ap, const unsigned short* __restrict__ Bp) {
+    unsigned long long st_t0 = 0, st_r0 = 0;
+    if (ABL & 8) { st_t0 = __builtin_amdgcn_s_memtime(); st_r0 = __builtin_amdgcn_s_memrealtime(); }
     constexpr int BM = WAVES_M * WM * 32, BN = WAVES_N * WN * 32, NT = WAVES_M * WAVES_N * 64, NW = NT / 64;
     constexpr int SA = BM * 96, SB = BN * 96, SLOT = SA + SB;
     __shared__ __attribute__((aligned(16))) char lds[3 * SLOT];
@@ -516,6 +520,10 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void kq(float* __restrict__
             if (!(ABL & 2)) dma(g + 3, u % 3);
             if (u & 1) { read_frags(f0, (u + 1) % 3); mfmas(f1); }
             else       { read_frags(f1, (u + 1) % 3); mfmas(f0); }
+            if ((ABL & 8) && u == 5 && base + 6 >= total && threadIdx.x == 0 && g_stamps) {
+                g_stamps[blockIdx.x * 4 + 0] = st_t0; g_stamps[blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memtime();
+                g_stamps[blockIdx.x * 4 + 2] = st_r0; g_stamps[blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memrealtime();
+            }
             if (u == 5) {                          // ns % 6 == 0: a tile can only end here
                 stage_in_tile += 6;
                 if (stage_in_tile == ns) {         // wave-uniform
@@ -553,6 +561,189 @@ void runq(float* C, int M, int N, int K, const unsigned short* Ap, const unsigne
     float best = 1e9;
     for (int rr = 0; rr < 6; ++rr) { hipEventRecord(e0); for (int i = 0; i < 10; ++i) go(); hipEventRecord(e1); hipEventSynchronize(e1); float ms; hipEventElapsedTime(&ms, e0, e1); if (ms / 10 < best) best = ms / 10; }
     printf("  v3 abl %d tile %3dx%-3d thr %3d grid %5d (tiles %d): %7.1f us  %6.1f TF(f32-eq)  maxdiff %.3g\n", ABL, BM, BN, NT, grid.x, tiles, best * 1e3, 2.0 * M * N * K / best / 1e9, md);
+    if (ABL & 8) {
+        unsigned long long* dbuf; hipMalloc(&dbuf, (size_t)grid.x * 32); hipMemset(dbuf, 0, (size_t)grid.x * 32);
+        hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &dbuf, sizeof(dbuf));
+        for (int i = 0; i < 200; ++i) go();          // sustained load first (DVFS settles), the last launch's stamps are read
+        hipDeviceSynchronize();
+        std::vector<unsigned long long> h((size_t)grid.x * 4); hipMemcpy(h.data(), dbuf, h.size() * 8, hipMemcpyDeviceToHost);
+        std::vector<double> ghz, us;
+        for (unsigned i = 0; i < grid.x; ++i) { const double dt = (double)(h[i * 4 + 1] - h[i * 4]), dr = (double)(h[i * 4 + 3] - h[i * 4 + 2]); if (dr > 0) { ghz.push_back(dt / dr * 0.1); us.push_back(dr / 100.0); } }
+        std::sort(ghz.begin(), ghz.end()); std::sort(us.begin(), us.end());
+        if (!ghz.empty()) printf("      in-kernel clock (s_memtime / s_memrealtime): median %.2f GHz (min %.2f, max %.2f); workgroup lifetime median %.1f us\n", ghz[ghz.size() / 2], ghz.front(), ghz.back(), us[us.size() / 2]);
+        dbuf = nullptr; hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &dbuf, sizeof(dbuf));
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// v4: v3 with WAVE SPECIALISATION -- waves [0, NC) consume (LDS fragment reads + MFMA + epilogue), waves [NC, NC + NL)
+// load (LDS-DMA only).  A DMA instruction blocks its wave's issue for ~100 cycles, during which that wave's MFMA
+// queue drains; loader waves absorb that stall while the consumers keep the matrix pipe fed.
+template <int WM, int WN, int WAVES_M, int WAVES_N, int NL, int ABL>
+__global__ __launch_bounds__((WAVES_M * WAVES_N + NL) * 64) void kr(float* __restrict__ C, int M, int N, int K,
+                                                                     const unsigned short* __restrict__ Ap, const unsigned short* __restrict__ Bp) {
+    constexpr int BM = WAVES_M * WM * 32, BN = WAVES_N * WN * 32, NC = WAVES_M * WAVES_N;
+    constexpr int SA = BM * 96, SB = BN * 96, SLOT = SA + SB, RING = 3;
+    __shared__ __attribute__((aligned(16))) char lds[RING * SLOT];
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), r = lane & 31, h = lane >> 5;
+    const bool loader = wave >= NC;
+    const int lw = wave - NC;                    // loader index
+    const int wm0 = (wave / WAVES_N) * WM * 32, wn0 = (wave % WAVES_N) * WN * 32;
+    const int tiles_n = N / BN, tiles_m = (M + BM - 1) / BM, ntiles = tiles_m * tiles_n;
+    const unsigned rowbytes = (unsigned)K * 6;
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(Ap), 0, (int)((long)M * rowbytes), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(Bp), 0, (int)((long)N * rowbytes), 0x00020000);
+    constexpr int QA = BM * 6 / 64, QB = BN * 6 / 64, QT = QA + QB, QW = (QT + NL - 1) / NL;
+    const int ns = K / 16;
+    const int my_tiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int total = my_tiles * ns;
+    if (total == 0) return;
+    auto tile_origin = [&](int j, int& bm0, int& bn0) {
+        const int tile = blockIdx.x + j * gridDim.x;
+        bm0 = (tile / tiles_n) * BM; bn0 = (tile % tiles_n) * BN;
+    };
+    if (loader) {
+        unsigned voff[QW];
+#pragma unroll
+        for (int i = 0; i < QW; ++i) {
+            const int q = lw + i * NL;
+            const bool isA = q < QA;
+            const int c = (isA ? q : q - QA) * 64 + lane, row = c / 6, w = c % 6, pl = w >> 1, kc = (w & 1) ^ ((row >> 3) & 1);
+            voff[i] = (unsigned)row * rowbytes + pl * 32 + kc * 16;
+        }
+        auto dma = [&](int g) {
+            if (g >= total) return;
+            const int j = g / ns, s = g - j * ns;
+            int bm0, bn0; tile_origin(j, bm0, bn0);
+            char* slot = lds + (g % RING) * SLOT;
+            const unsigned sa_off = (unsigned)bm0 * rowbytes + s * 96, sb_off = (unsigned)bn0 * rowbytes + s * 96;
+#pragma unroll
+            for (int i = 0; i < QW; ++i) {
+                const int q = lw + i * NL;
+                if (q < QA) dma16(rsA, slot + q * 1024, voff[i], sa_off);
+                else if (q < QT) dma16(rsB, slot + SA + (q - QA) * 1024, voff[i], sb_off);
+            }
+        };
+        // stage g is consumed in iteration g (between barrier g and barrier g + 1); its slot is refilled with stage g + 3
+        // after barrier g + 1.  Loader: before barrier g make sure stage g has landed (at most stages g + 1, g + 2 in flight).
+        dma(0); dma(1); dma(2);
+        for (int g = 0; g < total; ++g) {
+            asm volatile("s_waitcnt vmcnt(%0)" :: "n"(QT / NL) : "memory");     // stage g landed (at most stage g + 1 in flight)
+            __builtin_amdgcn_s_barrier();                                        // barrier g: consumers may read slot g % 3
+            if (g >= 1 && !(ABL & 2)) dma(g + 2);                                // slot (g - 1) % 3 was released by barrier g
+        }
+        __builtin_amdgcn_s_barrier();
+        return;
+    }
+    // ---- consumers
+    int fa[WM], fbo[WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i) { const int R = wm0 + i * 32 + r; fa[i] = R * 96 + ((h ^ ((R >> 3) & 1)) << 4); }
+#pragma unroll
+    for (int j = 0; j < WN; ++j) { const int R = wn0 + j * 32 + r; fbo[j] = SA + R * 96 + ((h ^ ((R >> 3) & 1)) << 4); }
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+    int stage_in_tile = 0, jtile = 0;
+    for (int g = 0; g < total; ++g) {
+        __builtin_amdgcn_s_barrier();                                            // barrier g
+        const char* slot = lds + (g % RING) * SLOT;
+        bf16x8 a[WM][3], b[WN][3];
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) a[i][pl] = *(const bf16x8*)(slot + fa[i] + pl * 32);
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) b[j][pl] = *(const bf16x8*)(slot + fbo[j] + pl * 32);
+        if (!(ABL & 4)) {
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j) {
+                    f32x16 c = acc[i][j];
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], c, 0, 0, 0);
+                    acc[i][j] = c;
+                }
+        }
+        if (++stage_in_tile == ns) {
+            int bm0, bn0; tile_origin(jtile, bm0, bn0);
+            if (!(ABL & 1)) {
+#pragma unroll
+                for (int i = 0; i < WM; ++i)
+#pragma unroll
+                    for (int jj = 0; jj < WN; ++jj) {
+                        const int n = bn0 + wn0 + jj * 32 + r;
+                        float* d = C + (long)(bm0 + wm0 + i * 32 + 4 * h) * N + n;
+                        if (bm0 + wm0 + i * 32 + 31 < M) {
+#pragma unroll
+                            for (int v = 0; v < 16; ++v) { *d = acc[i][jj][v]; d += (((v & 3) == 3) ? 5 : 1) * (long)N; }
+                        } else {
+#pragma unroll
+                            for (int v = 0; v < 16; ++v) {
+                                const int m = bm0 + wm0 + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
+                                if (m < M) C[(long)m * N + n] = acc[i][jj][v];
+                            }
+                        }
+                    }
+            } else {
+                float sacc = 0.f;
+#pragma unroll
+                for (int i = 0; i < WM; ++i)
+#pragma unroll
+                    for (int jj = 0; jj < WN; ++jj)
+#pragma unroll
+                        for (int v = 0; v < 16; ++v) sacc += acc[i][jj][v];
+                if (sacc == 12345.678f) C[t] = sacc;
+            }
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int jj = 0; jj < WN; ++jj)
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) acc[i][jj][v] = 0.f;
+            stage_in_tile = 0; ++jtile;
+        }
+    }
+    __builtin_amdgcn_s_barrier();
+}
+
+template <int WM, int WN, int WAVES_M, int WAVES_N, int NL, int ABL = 0>
+void runr(float* C, int M, int N, int K, const unsigned short* Ap, const unsigned short* Bp, int nwg = 256) {
+    constexpr int BM = WAVES_M * WM * 32, BN = WAVES_N * WN * 32, NT = (WAVES_M * WAVES_N + NL) * 64;
+    if (N % BN || K % 16) { printf("  v4 tile %3dx%-3d skipped\n", BM, BN); return; }
+    const int tiles = ((M + BM - 1) / BM) * (N / BN);
+    dim3 grid(tiles < nwg ? tiles : nwg);
+    auto go = [&]() { hipLaunchKernelGGL((kr<WM, WN, WAVES_M, WAVES_N, NL, ABL>), grid, dim3(NT), 0, 0, C, M, N, K, Ap, Bp); };
+    hipMemset(C, 0, (size_t)M * N * 4);
+    go(); hipDeviceSynchronize();
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { printf("  launch error %s\n", hipGetErrorString(e)); return; }
+    double md = 0;
+    if (g_ref2) {
+        std::vector<float> c1((size_t)64 * N), c2((size_t)64 * N);
+        for (int part = 0; part < 2; ++part) {
+            const size_t off = part ? (size_t)(M - 64) * N : 0;
+            hipMemcpy(c1.data(), C + off, c1.size() * 4, hipMemcpyDeviceToHost);
+            hipMemcpy(c2.data(), g_ref2 + off, c2.size() * 4, hipMemcpyDeviceToHost);
+            for (size_t i = 0; i < c1.size(); ++i) md = fmax(md, fabs((double)c1[i] - c2[i]));
+        }
+    }
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    float best = 1e9;
+    for (int rr = 0; rr < 6; ++rr) { hipEventRecord(e0); for (int i = 0; i < 10; ++i) go(); hipEventRecord(e1); hipEventSynchronize(e1); float ms; hipEventElapsedTime(&ms, e0, e1); if (ms / 10 < best) best = ms / 10; }
+    printf("  v4 abl %d tile %3dx%-3d consumers %d loaders %d grid %5d (tiles %d): %7.1f us  %6.1f TF(f32-eq)  maxdiff %.3g\n", ABL, BM, BN, WAVES_M * WAVES_N, NL, grid.x, tiles, best * 1e3, 2.0 * M * N * K / best / 1e9, md);
 }
 
 static void split_host16(const std::vector<float>& h, size_t rows, int K, std::vector<unsigned short>& out) {
@@ -603,15 +794,13 @@ int main(int argc, char** argv) {
     runp<2, 3, 2, 2, 3>(C, M, N, K, Ap, Bp);
     runq<2, 3, 2, 2, 0>(C, M, N, K, Ap, Bp);
     runq<2, 3, 2, 2, 1>(C, M, N, K, Ap, Bp);
-    runq<2, 3, 2, 2, 2>(C, M, N, K, Ap, Bp);
-    runq<2, 3, 2, 2, 3>(C, M, N, K, Ap, Bp);
-    runq<2, 3, 2, 2, 5>(C, M, N, K, Ap, Bp);
-    runq<1, 3, 2, 2, 0>(C, M, N, K, Ap, Bp);
-    runq<1, 3, 2, 2, 1>(C, M, N, K, Ap, Bp);
-    runq<1, 3, 2, 2, 0>(C, M, N, K, Ap, Bp, 512);
-    runq<1, 3, 4, 2, 0>(C, M, N, K, Ap, Bp);
-    runq<1, 3, 4, 2, 1>(C, M, N, K, Ap, Bp);
-    runq<2, 3, 4, 2, 0>(C, M, N, K, Ap, Bp);
-    runq<2, 3, 4, 2, 1>(C, M, N, K, Ap, Bp);
+    runr<2, 3, 2, 2, 4, 0>(C, M, N, K, Ap, Bp);
+    runr<2, 3, 2, 2, 4, 1>(C, M, N, K, Ap, Bp);
+    runr<2, 3, 2, 2, 4, 3>(C, M, N, K, Ap, Bp);
+    runr<2, 3, 2, 2, 2, 0>(C, M, N, K, Ap, Bp);
+    runr<2, 3, 2, 2, 2, 1>(C, M, N, K, Ap, Bp);
+    runr<2, 3, 2, 2, 1, 0>(C, M, N, K, Ap, Bp);
+    runr<1, 3, 4, 2, 4, 0>(C, M, N, K, Ap, Bp);
+    runr<1, 3, 4, 2, 4, 1>(C, M, N, K, Ap, Bp);
     return 0;
 }
