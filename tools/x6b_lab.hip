@@ -13,6 +13,7 @@
 #include <cstring>
 #include <cmath>
 #include <algorithm>
+#include <type_traits>
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -746,6 +747,209 @@ void runr(float* C, int M, int N, int K, const unsigned short* Ap, const unsigne
     printf("  v4 abl %d tile %3dx%-3d consumers %d loaders %d grid %5d (tiles %d): %7.1f us  %6.1f TF(f32-eq)  maxdiff %.3g\n", ABL, BM, BN, WAVES_M * WAVES_N, NL, grid.x, tiles, best * 1e3, 2.0 * M * N * K / best / 1e9, md);
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// v5: v4 + PING-PONG consumer groups.  Waves [0, NC) = group X, [NC, 2 NC) = group Y, then NL loader waves.  The
+// workgroup walks its tiles in order; tile j is computed by group j & 1 (one consumer wave per SIMD owns the matrix
+// pipe) while the OTHER group stores the tile it finished before, one twelfth of its accumulators per stage.
+// K % 192 == 0 (twelve stages per unrolled trip).
+template <int WM, int WN, int WAVES_M, int WAVES_N, int NL, int ABL>
+__global__ __launch_bounds__((2 * WAVES_M * WAVES_N + NL) * 64) void ks(float* __restrict__ C, int M, int N, int K,
+                                                                         const unsigned short* __restrict__ Ap, const unsigned short* __restrict__ Bp) {
+    constexpr int BM = WAVES_M * WM * 32, BN = WAVES_N * WN * 32, NC = WAVES_M * WAVES_N;
+    constexpr int SA = BM * 96, SB = BN * 96, SLOT = SA + SB, RING = 3;
+    static_assert(WM * WN * 2 == 12, "twelve epilogue chunks");
+    __shared__ __attribute__((aligned(16))) char lds[RING * SLOT];
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), r = lane & 31, h = lane >> 5;
+    const int grp = wave / NC;                   // 0 = X, 1 = Y, >= 2 loaders
+    const int cw = wave % NC, lw = wave - 2 * NC;
+    const int wm0 = (cw / WAVES_N) * WM * 32, wn0 = (cw % WAVES_N) * WN * 32;
+    const int tiles_n = N / BN, tiles_m = (M + BM - 1) / BM, ntiles = tiles_m * tiles_n;
+    const unsigned rowbytes = (unsigned)K * 6;
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(Ap), 0, (int)((long)M * rowbytes), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(Bp), 0, (int)((long)N * rowbytes), 0x00020000);
+    constexpr int QA = BM * 6 / 64, QB = BN * 6 / 64, QT = QA + QB, QW = (QT + NL - 1) / NL;
+    const int ns = K / 16;
+    const int my_tiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int total = my_tiles * ns;
+    if (total == 0) return;
+    auto tile_origin = [&](int j, int& bm0, int& bn0) {
+        const int tile = blockIdx.x + j * gridDim.x;
+        bm0 = (tile / tiles_n) * BM; bn0 = (tile % tiles_n) * BN;
+    };
+    if (grp >= 2) {
+        unsigned voff[QW];
+#pragma unroll
+        for (int i = 0; i < QW; ++i) {
+            const int q = lw + i * NL;
+            const bool isA = q < QA;
+            const int c = (isA ? q : q - QA) * 64 + lane, row = c / 6, w = c % 6, pl = w >> 1, kc = (w & 1) ^ ((row >> 3) & 1);
+            voff[i] = (unsigned)row * rowbytes + pl * 32 + kc * 16;
+        }
+        auto dma = [&](int g) {
+            if (g >= total) return;
+            const int j = g / ns, s = g - j * ns;
+            int bm0, bn0; tile_origin(j, bm0, bn0);
+            char* slot = lds + (g % RING) * SLOT;
+            const unsigned sa_off = (unsigned)bm0 * rowbytes + s * 96, sb_off = (unsigned)bn0 * rowbytes + s * 96;
+#pragma unroll
+            for (int i = 0; i < QW; ++i) {
+                const int q = lw + i * NL;
+                if (q < QA) dma16(rsA, slot + q * 1024, voff[i], sa_off);
+                else if (q < QT) dma16(rsB, slot + SA + (q - QA) * 1024, voff[i], sb_off);
+            }
+        };
+        dma(0); dma(1); dma(2);
+        for (int g = 0; g < total; ++g) {
+            asm volatile("s_waitcnt vmcnt(%0)" :: "n"(QT / NL) : "memory");
+            __builtin_amdgcn_s_barrier();
+            if (g >= 1 && !(ABL & 2)) dma(g + 2);
+        }
+        __builtin_amdgcn_s_barrier();
+        return;
+    }
+    // ---- consumers
+    int fa[WM], fbo[WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i) { const int R = wm0 + i * 32 + r; fa[i] = R * 96 + ((h ^ ((R >> 3) & 1)) << 4); }
+#pragma unroll
+    for (int j = 0; j < WN; ++j) { const int R = wn0 + j * 32 + r; fbo[j] = SA + R * 96 + ((h ^ ((R >> 3) & 1)) << 4); }
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+    int g = 0;
+    bool pending = false;
+    int pm0 = 0, pn0 = 0;                                   // origin of the tile whose accumulators wait to be stored
+    auto store_chunk = [&](auto uc) {                        // chunk u: accumulator tile u / 2, registers 8 (u & 1) .. + 7
+        constexpr int u = decltype(uc)::value;
+        constexpr int i = (u / 2) / WN, jj = (u / 2) % WN, v0 = (u & 1) * 8;
+        if (ABL & 1) {
+            float sacc = 0.f;
+#pragma unroll
+            for (int v = 0; v < 8; ++v) sacc += acc[i][jj][v0 + v];
+            if (sacc == 12345.678f) C[t] = sacc;
+            return;
+        }
+        const int n = pn0 + wn0 + jj * 32 + r;
+        const int mb = pm0 + wm0 + i * 32 + 4 * h + (v0 ? 16 : 0);        // registers 8..15 hold rows 16 + ...
+        float* d = C + (long)mb * N + n;
+        if (pm0 + wm0 + i * 32 + 31 < M) {
+#pragma unroll
+            for (int v = 0; v < 8; ++v) { *d = acc[i][jj][v0 + v]; d += (((v & 3) == 3) ? 5 : 1) * (long)N; }
+        } else {
+#pragma unroll
+            for (int v = 0; v < 8; ++v) {
+                const int m = mb + (v & 3) + 8 * (v >> 2);
+                if (m < M) C[(long)m * N + n] = acc[i][jj][v0 + v];
+            }
+        }
+    };
+    auto compute_stage = [&]() {
+        __builtin_amdgcn_s_barrier();
+        const char* slot = lds + (g % RING) * SLOT;
+        bf16x8 a[WM][3];
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) a[i][pl] = *(const bf16x8*)(slot + fa[i] + pl * 32);
+        // one column block of B fragments at a time (12 instead of 36 registers live): the budget is 168 registers
+        // per wave with 12 waves per CU
+#pragma unroll
+        for (int jj = 0; jj < WN; ++jj) {
+            bf16x8 b[3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) b[pl] = *(const bf16x8*)(slot + fbo[jj] + pl * 32);
+            if (!(ABL & 4)) {
+#pragma unroll
+                for (int i = 0; i < WM; ++i) {
+                    f32x16 c = acc[i][jj];
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[2], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[0], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[0], c, 0, 0, 0);
+                    acc[i][jj] = c;
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        ++g;
+    };
+    for (int j = 0; j < my_tiles; ++j) {
+        const bool mine = (j & 1) == grp;
+        if (mine) {
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int jj = 0; jj < WN; ++jj)
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) acc[i][jj][v] = 0.f;
+            for (int s2 = 0; s2 < ns; ++s2) compute_stage();
+        } else {
+            // the other group owns the matrix pipe: store the finished tile, one chunk per stage, and keep in step
+            if (pending) {
+                __builtin_amdgcn_s_barrier(); store_chunk(std::integral_constant<int, 0>{});
+                __builtin_amdgcn_s_barrier(); store_chunk(std::integral_constant<int, 1>{});
+                __builtin_amdgcn_s_barrier(); store_chunk(std::integral_constant<int, 2>{});
+                __builtin_amdgcn_s_barrier(); store_chunk(std::integral_constant<int, 3>{});
+                __builtin_amdgcn_s_barrier(); store_chunk(std::integral_constant<int, 4>{});
+                __builtin_amdgcn_s_barrier(); store_chunk(std::integral_constant<int, 5>{});
+                __builtin_amdgcn_s_barrier(); store_chunk(std::integral_constant<int, 6>{});
+                __builtin_amdgcn_s_barrier(); store_chunk(std::integral_constant<int, 7>{});
+                __builtin_amdgcn_s_barrier(); store_chunk(std::integral_constant<int, 8>{});
+                __builtin_amdgcn_s_barrier(); store_chunk(std::integral_constant<int, 9>{});
+                __builtin_amdgcn_s_barrier(); store_chunk(std::integral_constant<int, 10>{});
+                __builtin_amdgcn_s_barrier(); store_chunk(std::integral_constant<int, 11>{});
+                for (int s2 = 12; s2 < ns; ++s2) __builtin_amdgcn_s_barrier();
+            } else {
+                for (int s2 = 0; s2 < ns; ++s2) __builtin_amdgcn_s_barrier();
+            }
+            g += ns;
+        }
+        if (mine) { pending = true; tile_origin(j, pm0, pn0); }
+        else pending = false;
+    }
+    if (pending) {
+        store_chunk(std::integral_constant<int, 0>{}); store_chunk(std::integral_constant<int, 1>{}); store_chunk(std::integral_constant<int, 2>{});
+        store_chunk(std::integral_constant<int, 3>{}); store_chunk(std::integral_constant<int, 4>{}); store_chunk(std::integral_constant<int, 5>{});
+        store_chunk(std::integral_constant<int, 6>{}); store_chunk(std::integral_constant<int, 7>{}); store_chunk(std::integral_constant<int, 8>{});
+        store_chunk(std::integral_constant<int, 9>{}); store_chunk(std::integral_constant<int, 10>{}); store_chunk(std::integral_constant<int, 11>{});
+    }
+    __builtin_amdgcn_s_barrier();
+}
+
+template <int WM, int WN, int WAVES_M, int WAVES_N, int NL, int ABL = 0>
+void runs(float* C, int M, int N, int K, const unsigned short* Ap, const unsigned short* Bp, int nwg = 256) {
+    constexpr int BM = WAVES_M * WM * 32, BN = WAVES_N * WN * 32, NT = (2 * WAVES_M * WAVES_N + NL) * 64;
+    if (N % BN || K % 192) { printf("  v5 tile %3dx%-3d skipped\n", BM, BN); return; }
+    const int tiles = ((M + BM - 1) / BM) * (N / BN);
+    dim3 grid(tiles < nwg ? tiles : nwg);
+    auto go = [&]() { hipLaunchKernelGGL((ks<WM, WN, WAVES_M, WAVES_N, NL, ABL>), grid, dim3(NT), 0, 0, C, M, N, K, Ap, Bp); };
+    hipMemset(C, 0, (size_t)M * N * 4);
+    go(); hipDeviceSynchronize();
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { printf("  launch error %s\n", hipGetErrorString(e)); return; }
+    double md = 0;
+    if (g_ref2) {
+        std::vector<float> c1((size_t)64 * N), c2((size_t)64 * N);
+        for (int part = 0; part < 2; ++part) {
+            const size_t off = part ? (size_t)(M - 64) * N : 0;
+            hipMemcpy(c1.data(), C + off, c1.size() * 4, hipMemcpyDeviceToHost);
+            hipMemcpy(c2.data(), g_ref2 + off, c2.size() * 4, hipMemcpyDeviceToHost);
+            for (size_t i = 0; i < c1.size(); ++i) md = fmax(md, fabs((double)c1[i] - c2[i]));
+        }
+    }
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    float best = 1e9;
+    for (int rr = 0; rr < 6; ++rr) { hipEventRecord(e0); for (int i = 0; i < 10; ++i) go(); hipEventRecord(e1); hipEventSynchronize(e1); float ms; hipEventElapsedTime(&ms, e0, e1); if (ms / 10 < best) best = ms / 10; }
+    printf("  v5 abl %d tile %3dx%-3d 2x%d consumers, %d loaders, grid %5d (tiles %d): %7.1f us  %6.1f TF(f32-eq)  maxdiff %.3g\n", ABL, BM, BN, WAVES_M * WAVES_N, NL, grid.x, tiles, best * 1e3, 2.0 * M * N * K / best / 1e9, md);
+}
+
 static void split_host16(const std::vector<float>& h, size_t rows, int K, std::vector<unsigned short>& out) {
     out.assign(rows * K * 3, 0);
     for (size_t rw = 0; rw < rows; ++rw)
@@ -792,15 +996,11 @@ int main(int argc, char** argv) {
     runp<2, 3, 2, 2, 0>(C, M, N, K, Ap, Bp);
     runp<2, 3, 2, 2, 1>(C, M, N, K, Ap, Bp);
     runp<2, 3, 2, 2, 3>(C, M, N, K, Ap, Bp);
-    runq<2, 3, 2, 2, 0>(C, M, N, K, Ap, Bp);
-    runq<2, 3, 2, 2, 1>(C, M, N, K, Ap, Bp);
     runr<2, 3, 2, 2, 4, 0>(C, M, N, K, Ap, Bp);
     runr<2, 3, 2, 2, 4, 1>(C, M, N, K, Ap, Bp);
-    runr<2, 3, 2, 2, 4, 3>(C, M, N, K, Ap, Bp);
-    runr<2, 3, 2, 2, 2, 0>(C, M, N, K, Ap, Bp);
-    runr<2, 3, 2, 2, 2, 1>(C, M, N, K, Ap, Bp);
-    runr<2, 3, 2, 2, 1, 0>(C, M, N, K, Ap, Bp);
-    runr<1, 3, 4, 2, 4, 0>(C, M, N, K, Ap, Bp);
-    runr<1, 3, 4, 2, 4, 1>(C, M, N, K, Ap, Bp);
+    runs<2, 3, 2, 2, 4, 0>(C, M, N, K, Ap, Bp);
+    runs<2, 3, 2, 2, 4, 1>(C, M, N, K, Ap, Bp);
+    runs<2, 3, 2, 2, 4, 3>(C, M, N, K, Ap, Bp);
+    runs<2, 3, 2, 2, 2, 0>(C, M, N, K, Ap, Bp);
     return 0;
 }
