@@ -136,6 +136,9 @@ int vsom_attention_fwd(const float* qkv, float* out, float* lse, int B, int N, i
 int vsom_attention_bwd(const float* qkv, const float* out, const float* dout, const float* lse,
                        float* dqkv, float* delta_ws, int B, int N, int H, int hd,
                        vsom_stream_t stream);
+/* test hook: 0 = run the short-sequence backward as two launches (dQ, then dK/dV) instead of the fused one;
+   results are bit-identical either way (the GPU suite checks) */
+int vsom_set_attention_fused(int fused);
 
 /* ------------------------------------------------------------------ SOM layer */
 /* inv_norm[r] = 1 / max(||X[r,:]||_2, eps)   -- F.normalize(p=2, eps=1e-12), som_layer.py:120-121 */

@@ -191,18 +191,21 @@ def test_steps_are_deterministic():
     assert torch.equal(outs[0], outs[1])
 
 
-def test_stream_level_concurrency_is_bitwise_identical(monkeypatch):
+def test_stream_level_concurrency_is_bitwise_identical():
     """Weight-gradient GEMMs and the SOM backward run on side streams, and the forward runs as two
     half-batch chains on two streams (model.py).  Arithmetic and summation order are unchanged, so 8
     training steps at CIFAR layer shapes must end in bit-identical parameters with every combination
     of the switches -- any missed ordering edge would show up here."""
     import vit_som_amd
     from oracle.gen_golden import make_config
+    from vit_som_amd import ops
+    from vit_som_amd.tuning import hooks
     cfg = make_config(3, 32, 4, 192, 4, 3, 96, 2, (12, 12), 0, 96)
     finals = []
-    for side, split in (("0", "0"), ("1", "1"), ("1", "0"), ("0", "1")):
-        monkeypatch.setenv("VSOM_SIDE_STREAM", side)
-        monkeypatch.setenv("VSOM_FWD_SPLIT", split)
+    for side, split, nblk, fused in (("0", "0", None, True), ("1", "1", None, True), ("1", "0", None, False), ("0", "1", 2, True),
+                                     ("1", "1", 1, False)):
+        hooks.set(side_stream=side == "1", fwd_split=split == "1", fwd_split_blocks=nblk)
+        ops.set_attention_fused(fused)
         torch.manual_seed(0)
         m = vit_som_amd.ViTSOM(copy.deepcopy(cfg), device=DEV)
         m.set_schedule(5000, 500)
@@ -218,6 +221,8 @@ def test_stream_level_concurrency_is_bitwise_identical(monkeypatch):
         assert (m.vit.__dict__.get("_fwd_side") is not None) == (split == "1")
         assert split == "0" or m.vit._fwd_side is m._side_stream          # the second chain borrows the backward's side stream
         finals.append(m.arena.params.clone())
+    hooks.reset()
+    ops.set_attention_fused(True)
     assert all(torch.equal(finals[0], f) for f in finals[1:])
 
 

@@ -1,10 +1,19 @@
 """A/B timing of the whole training step inside ONE process (box-to-box and clock drift cancel):
-alternates environment settings between blocks of steps.  usage: ab_step.py KEY=a,b [steps] [rounds]"""
+alternates one test hook (vit_som_amd/tuning.py) between blocks of steps.  usage: ab_step.py hook=a,b [steps] [rounds]
+e.g. ab_step.py fwd_split_blocks=0,6,12   ab_step.py side_stream=0,1   ab_step.py attn_fused=0,1"""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench
-from vit_som_amd import ViTSOM
+from vit_som_amd import ViTSOM, ops
+from vit_som_amd.tuning import hooks
+
+
+def apply(key, v):
+    if key == "attn_fused":
+        ops.set_attention_fused(bool(int(v)))
+    else:
+        hooks.set(**{key: (None if v == "None" else int(v))})
 
 key, vals = sys.argv[1].split("=")
 vals = vals.split(",")
@@ -26,10 +35,10 @@ def run(n):
 
 res = {v: [] for v in vals}
 for v in vals:
-    os.environ[key] = v; run(3)
+    apply(key, v); run(3)
 for r in range(rounds):
     for v in vals:
-        os.environ[key] = v
+        apply(key, v)
         run(2)
         res[v].append(run(steps))
 for v in vals:

@@ -17,7 +17,8 @@ def run(n):
     return 1e3 * (time.perf_counter() - t0) / n
 for r in range(3):
     for val in ("0", "6", "12"):
-        os.environ["VSOM_FWD_SPLIT_BLOCKS"] = val
+        from vit_som_amd.tuning import hooks
+        hooks.set(fwd_split_blocks=int(val))
         run(3)
         ops.enable_timer("bmu_cosine_dots")
         t = run(20)

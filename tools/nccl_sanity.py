@@ -15,7 +15,8 @@ import bench
 from vit_som_amd import ViTSOM
 
 def run(overlap, steps=6):
-    os.environ["VSOM_OVERLAP_ALLREDUCE"] = "1" if overlap else "0"
+    from vit_som_amd.tuning import hooks
+    hooks.set(overlap_allreduce=bool(overlap))
     torch.manual_seed(0)
     m = ViTSOM(bench.c3_config(128), device="cuda")
     m.set_schedule(50000, 1000)

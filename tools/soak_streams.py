@@ -5,8 +5,8 @@ import bench
 from vit_som_amd import ViTSOM
 finals = []
 for side in ("0", "1", "1"):
-    os.environ["VSOM_SIDE_STREAM"] = side
-    os.environ["VSOM_FWD_SPLIT"] = side
+    from vit_som_amd.tuning import hooks
+    hooks.set(side_stream=side == "1", fwd_split=side == "1")
     torch.manual_seed(0)
     m = ViTSOM(bench.c3_config(512), device="cuda")
     m.set_schedule(50000, 10000); m._it = 1000

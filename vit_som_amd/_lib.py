@@ -45,6 +45,7 @@ SIGNATURES = {
     "vsom_layernorm_bwd": (C.c_int, [c_fp] * 9 + [C.c_int, C.c_int, c_fp, C.c_size_t, c_stream]),
     "vsom_attention_fwd": (C.c_int, [c_fp, c_fp, c_fp, C.c_int, C.c_int, C.c_int, C.c_int, c_stream]),
     "vsom_attention_bwd": (C.c_int, [c_fp] * 6 + [C.c_int] * 4 + [c_stream]),
+    "vsom_set_attention_fused": (C.c_int, [C.c_int]),
     "vsom_row_inv_norm": (C.c_int, [c_fp, C.c_long, C.c_int, C.c_int, C.c_float, c_fp, c_stream]),
     "vsom_row_sqnorm": (C.c_int, [c_fp, C.c_long, C.c_int, C.c_int, c_fp, c_stream]),
     "vsom_bmu_euclid_fwd": (C.c_int, [c_fp, C.c_long, c_fp, c_fp, c_fp, c_fp, c_fp, C.c_int, C.c_int, C.c_int, c_fp,

@@ -22,8 +22,13 @@
 // additional wave with VALU only (lane per key for the dots, lane per channel for the sums).
 #include "common.h"
 
+#include <atomic>
+
 #include <stdlib.h>
 namespace vsom {
+
+// test hook (vsom_set_attention_fused): 0 keeps the short-sequence backward as two launches
+static std::atomic<int> g_attn_fused{1};
 
 constexpr int MAXCH = 5;   // EXTRA mode: the VALU wave walks the rows in chunks of 64 -> N <= 320
 
@@ -884,7 +889,7 @@ static int launch_bwd_t(const float* qkv, const float* out, const float* dout, c
     const dim3 block(64 * (attn_waves(N) + (EXTRA ? 1 : 0)));
     // all four slices in LDS and still two workgroups per CU -> one fused launch (vector path only)
     const size_t fused_lds = attn_fused_lds_bytes(N, HDP);
-    if (ACfg<HDP>::VEC && fused_lds <= 80 * 1024 && !(getenv("VSOM_ATTN_FUSED") && !atoi(getenv("VSOM_ATTN_FUSED")))) {
+    if (ACfg<HDP>::VEC && fused_lds <= 80 * 1024 && g_attn_fused.load(std::memory_order_relaxed)) {
         hipLaunchKernelGGL((attn_bwd_fused_kernel<HDP, EXTRA>), dim3(B * H), block, fused_lds, st, qkv, out, dout, lse, dqkv,
                            delta, N, H, hd, scale);
         VSOM_LAUNCH_CHECK("attn_bwd_fused_kernel");
@@ -923,6 +928,11 @@ static int attn_check(const char* who, int B, int N, int H, int hd, int* hdp) {
 using namespace vsom;
 
 extern "C" {
+
+int vsom_set_attention_fused(int fused) {
+    g_attn_fused.store(fused ? 1 : 0, std::memory_order_relaxed);
+    return VSOM_OK;
+}
 
 int vsom_attention_fwd(const float* qkv, float* out, float* lse, int B, int N, int H, int hd, vsom_stream_t stream) {
     VSOM_REQUIRE(qkv && out && lse, VSOM_EINVAL, "attention_fwd: null pointer");

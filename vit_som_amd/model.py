@@ -24,6 +24,7 @@ import torch.nn as nn
 from . import ops
 from ._lib import on_stream
 from .arena import ParamArena
+from .tuning import hooks
 
 try:  # the reference subclasses pl.LightningModule; do the same when Lightning is importable
     import pytorch_lightning as pl  # type: ignore
@@ -275,7 +276,7 @@ class ViTAutoencoder(nn.Module):
                             self.cls_token.view(E), a.tok0, a.xp, p)
         cur = a.tok0
         side = None
-        if cur.is_cuda and a.B % 2 == 0 and a.B >= 64 and os.environ.get("VSOM_FWD_SPLIT", "1") != "0":
+        if cur.is_cuda and a.B % 2 == 0 and a.B >= 64 and hooks.fwd_split:
             # the owner (ViTSOM) lends the stream its backward uses for the weight gradients -- idle during
             # the forward; a stream of its own would compete for the few hardware queues of the process
             # (measured: erratic, sometimes slower than one chain)
@@ -305,7 +306,7 @@ class ViTAutoencoder(nn.Module):
             # All blocks by default (A/B in one process, round 2: 0 / 6 / 12 of 12 blocks split -> 11.77 / 11.81 /
             # 11.68 ms per step; round 1 kept it to half because the f32-MFMA BMU pass ran slower right after a dense
             # forward -- the bf16 BMU pass does not).
-            nsplit = int(os.environ.get("VSOM_FWD_SPLIT_BLOCKS", str(len(self.blocks))))
+            nsplit = len(self.blocks) if hooks.fwd_split_blocks is None else int(hooks.fwd_split_blocks)
             nsplit = max(0, min(nsplit, len(self.blocks)))
             # enqueue the two chains alternately, block by block: the host feeds both streams at the same pace (all
             # of chain 0 first left the second stream idle for the ~0.7 ms the host needs to enqueue six blocks)
@@ -937,7 +938,7 @@ class _ArenaOwner:
     # own stream) overlaps the rest of the backward; allreduce_gradients() reduces what is left and
     # makes the consumer stream wait for every piece.  Under torch.distributed "nccl" == RCCL over xGMI.
     def _overlap_enabled(self) -> bool:
-        return self.world_size > 1 and os.environ.get("VSOM_OVERLAP_ALLREDUCE", "1") != "0"
+        return self.world_size > 1 and hooks.overlap_allreduce
 
     def _exchange_reset(self):
         self._works, self._started = [], []
@@ -1227,7 +1228,7 @@ class ViTSOM(_ArenaOwner, _Base):
         if dec and not self.classification:
             out["decoder"] = self._arena_span(dec[0], dec[-1])
         D = len(self.vit.blocks)
-        step = max(1, int(os.environ.get("VSOM_BUCKET_BLOCKS", "3")))
+        step = max(1, int(hooks.bucket_blocks))
         hi_name = "vit.norm.bias"
         for i in range(D - step, 0, -step):                 # blocks [i, i + step) (+ the final norm for the top bucket)
             out[f"enc{i}"] = self._arena_span(f"vit.blocks.{i}.norm1.weight", hi_name)
@@ -1241,7 +1242,7 @@ class ViTSOM(_ArenaOwner, _Base):
         x, a, s = self._ctx
         self._grads_reduced = False
         self._exchange_reset()
-        if x.is_cuda and os.environ.get("VSOM_SIDE_STREAM", "1") != "0":
+        if x.is_cuda and hooks.side_stream:
             self._ensure_streams(x.device)
             self.vit._side = self._side_stream
         else:

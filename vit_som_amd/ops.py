@@ -383,6 +383,11 @@ def fill(t, value):
     return t
 
 
+def set_attention_fused(fused: bool):
+    """Test hook: False runs the short-sequence attention backward as two launches."""
+    check(lib.vsom_set_attention_fused(int(bool(fused))), "vsom_set_attention_fused")
+
+
 def scaled_mul(out, a, b=None, scale_dev=None, factor=1.0):
     """out = factor * scale_dev[0] * a * b  (b / scale_dev optional)."""
     _f32(out, "out"); _f32(a, "a")

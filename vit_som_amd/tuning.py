@@ -1,0 +1,29 @@
+"""Test and measurement hooks -- NOT a configuration surface.
+
+The product always runs with these defaults; the GPU suite flips them to prove that the stream-level
+concurrency, the forward split and the overlapped exchange leave the result bit-identical, and the A/B tools
+under tools/ use them to time one variant against another inside one process.  (Round 1 read environment
+variables at these points, some of them inside the C library on every launch.)"""
+
+
+class _Hooks:
+    side_stream = True          # weight-gradient GEMMs and the SOM backward on side streams
+    fwd_split = True            # forward as two half-batch chains on two streams
+    fwd_split_blocks = None     # how many encoder blocks run as two chains (None = all)
+    overlap_allreduce = True    # N > 1: issue the all-reduce pieces inside the backward pass
+    bucket_blocks = 3           # encoder blocks per early all-reduce piece
+
+    def set(self, **kw):
+        for k, v in kw.items():
+            if not hasattr(_Hooks, k):
+                raise AttributeError(f"unknown hook {k!r}")
+            setattr(self, k, v)
+        return self
+
+    def reset(self):
+        for k in list(self.__dict__):
+            delattr(self, k)
+        return self
+
+
+hooks = _Hooks()
