@@ -950,6 +950,208 @@ void runs(float* C, int M, int N, int K, const unsigned short* Ap, const unsigne
     printf("  v5 abl %d tile %3dx%-3d 2x%d consumers, %d loaders, grid %5d (tiles %d): %7.1f us  %6.1f TF(f32-eq)  maxdiff %.3g\n", ABL, BM, BN, WAVES_M * WAVES_N, NL, grid.x, tiles, best * 1e3, 2.0 * M * N * K / best / 1e9, md);
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// v6: wave specialisation with fp32 operands in HBM (no planes anywhere): NL loader waves load both fp32 tiles
+// (k-contiguous, 128 B per row and 32-deep stage), split them into the three bf16 planes and store them into a
+// two-slot LDS ring (the swizzled 64-byte-row image of gemm_x6.h); NC consumer waves only read fragments and issue
+// MFMAs (72 per stage) and store the results.  Persistent workgroups, one per CU.  K % 32 == 0.
+__device__ __forceinline__ int v6_chunk_off(int row, int chunk) { return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4); }
+__device__ __forceinline__ int v6_piece_off(int row, int kq) { return v6_chunk_off(row, kq >> 1) + ((kq & 1) << 3); }
+
+template <int WM, int WN, int WAVES_M, int WAVES_N, int NL, int ABL>
+__global__ __launch_bounds__((WAVES_M * WAVES_N + NL) * 64) void kt6(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C,
+                                                                      int M, int N, int K) {
+    constexpr int BM = WAVES_M * WM * 32, BN = WAVES_N * WN * 32, NC = WAVES_M * WAVES_N, LT = NL * 64;
+    constexpr int PA = BM * 64, PB = BN * 64, SLOT = 3 * (PA + PB);
+    __shared__ __attribute__((aligned(16))) char lds[2 * SLOT];
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), r = lane & 31, h = lane >> 5;
+    const bool loader = wave >= NC;
+    const int wm0 = (wave / WAVES_N) * WM * 32, wn0 = (wave % WAVES_N) * WN * 32;
+    const int tiles_n = N / BN, tiles_m = (M + BM - 1) / BM, ntiles = tiles_m * tiles_n;
+    const int ns = K / 32;
+    const int my_tiles = (ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int total = my_tiles * ns;
+    if (total == 0) return;
+    auto tile_origin = [&](int j, int& bm0, int& bn0) {
+        const int tile = blockIdx.x + j * gridDim.x;
+        bm0 = (tile / tiles_n) * BM; bn0 = (tile % tiles_n) * BN;
+    };
+    if (loader) {
+        const int lt = t - NC * 64;                 // loader thread id
+        const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(A), 0, (int)((long)M * K * 4), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(B), 0, (int)((long)N * K * 4), 0x00020000);
+        // float4 number f = i * LT + lt of a [rows][8] tile: row = f >> 3, kq = f & 7 (k = 4 kq)
+        constexpr int FA = BM * 8 / LT, FB = BN * 8 / LT;
+        static_assert((BM * 8) % LT == 0 && (BN * 8) % LT == 0, "loader float4 count");
+        unsigned oa[FA], ob[FB];
+        int la[FA], lb[FB];
+#pragma unroll
+        for (int i = 0; i < FA; ++i) { const int f = i * LT + lt, row = f >> 3, kq = f & 7; oa[i] = (unsigned)(((long)row * K + 4 * kq) * 4); la[i] = v6_piece_off(row, kq); }
+#pragma unroll
+        for (int i = 0; i < FB; ++i) { const int f = i * LT + lt, row = f >> 3, kq = f & 7; ob[i] = (unsigned)(((long)row * K + 4 * kq) * 4); lb[i] = 3 * PA + v6_piece_off(row, kq); }
+        // DEPTH register sets: the global loads run DEPTH stages ahead of the LDS stores (the LDS ring has two slots)
+        constexpr int DEPTH = 4;
+        struct RS { f32x4 a[FA], b[FB]; };
+        RS R0, R1, R2, R3;
+        auto gload = [&](RS& R, int g) {
+            // UNCONDITIONAL (a stage past the end re-loads the last one): with a branch around the loads hipcc cannot
+            // count them and waits vmcnt(0) before every use -- the prefetch depth collapses to one stage
+            if (ABL & 2) return;
+            g = g < total ? g : total - 1;
+            const int j = g / ns;
+            int s2 = g - j * ns;
+            if (ABL & 16) { s2 += (int)(blockIdx.x % ns); if (s2 >= ns) s2 -= ns; }      // rotate the k order per workgroup: no two neighbours read the same weight lines at the same time
+            int bm0, bn0; tile_origin(j, bm0, bn0);
+            const unsigned sa = (unsigned)(((long)bm0 * K + s2 * 32) * 4), sb = (unsigned)(((long)bn0 * K + s2 * 32) * 4);
+#pragma unroll
+            for (int i = 0; i < FA; ++i) R.a[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, oa[i], sa, 0));
+#pragma unroll
+            for (int i = 0; i < FB; ++i) R.b[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsB, ob[i], sb, 0));
+        };
+        auto lstore = [&](const RS& R, int g) {
+            char* slot = lds + (g & 1) * SLOT;
+#pragma unroll
+            for (int i = 0; i < FA; ++i) {
+                uint2 p1, p2, p3; split3(R.a[i], p1, p2, p3);
+                *(uint2*)(slot + la[i]) = p1; *(uint2*)(slot + PA + la[i]) = p2; *(uint2*)(slot + 2 * PA + la[i]) = p3;
+            }
+#pragma unroll
+            for (int i = 0; i < FB; ++i) {
+                uint2 p1, p2, p3; split3(R.b[i], p1, p2, p3);
+                *(uint2*)(slot + lb[i]) = p1; *(uint2*)(slot + PB + lb[i]) = p2; *(uint2*)(slot + 2 * PB + lb[i]) = p3;
+            }
+        };
+        // stage g lives in slot g & 1 and register set g % DEPTH; consumers read it between barrier g and barrier g + 1
+        gload(R0, 0); gload(R1, 1); gload(R2, 2); gload(R3, 3);
+        lstore(R0, 0);
+        gload(R0, 4);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                           // barrier 0: stage 0 is readable
+        // iteration for stage k = g + 1 (k % 4 = 1, 2, 3, 0): store stage k (slot released by barrier k - 1), reload its
+        // register set with stage k + DEPTH, publish with barrier k
+#define V6_STEP(RSET, k)                                                  \
+        if ((k) >= total) break;                                         \
+        lstore(RSET, (k));                                               \
+        gload(RSET, (k) + DEPTH);                                        \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               \
+        __builtin_amdgcn_s_barrier();
+        for (int g = 0; ; g += 4) {
+            V6_STEP(R1, g + 1)
+            V6_STEP(R2, g + 2)
+            V6_STEP(R3, g + 3)
+            V6_STEP(R0, g + 4)
+        }
+#undef V6_STEP
+        return;
+    }
+    // ---- consumers
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+    int stage_in_tile = 0, jtile = 0;
+    for (int g = 0; g < total; ++g) {
+        __builtin_amdgcn_s_barrier();                                            // barrier g
+        const char* slot = lds + (g & 1) * SLOT;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 a[WM][3], b[WN][3];
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) a[i][pl] = *(const bf16x8*)(slot + pl * PA + v6_chunk_off(wm0 + i * 32 + r, 2 * ks + h));
+#pragma unroll
+            for (int j = 0; j < WN; ++j)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) b[j][pl] = *(const bf16x8*)(slot + 3 * PA + pl * PB + v6_chunk_off(wn0 + j * 32 + r, 2 * ks + h));
+            if (!(ABL & 4)) {
+#pragma unroll
+                for (int i = 0; i < WM; ++i)
+#pragma unroll
+                    for (int j = 0; j < WN; ++j) {
+                        f32x16 c = acc[i][j];
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], c, 0, 0, 0);
+                        acc[i][j] = c;
+                    }
+            }
+        }
+        if (++stage_in_tile == ns) {
+            int bm0, bn0; tile_origin(jtile, bm0, bn0);
+            if (!(ABL & 1)) {
+#pragma unroll
+                for (int i = 0; i < WM; ++i)
+#pragma unroll
+                    for (int jj = 0; jj < WN; ++jj) {
+                        const int n = bn0 + wn0 + jj * 32 + r;
+                        float* d = C + (long)(bm0 + wm0 + i * 32 + 4 * h) * N + n;
+                        if (bm0 + wm0 + i * 32 + 31 < M) {
+#pragma unroll
+                            for (int v = 0; v < 16; ++v) { *d = acc[i][jj][v]; d += (((v & 3) == 3) ? 5 : 1) * (long)N; }
+                        } else {
+#pragma unroll
+                            for (int v = 0; v < 16; ++v) {
+                                const int m = bm0 + wm0 + i * 32 + (v & 3) + 8 * (v >> 2) + 4 * h;
+                                if (m < M) C[(long)m * N + n] = acc[i][jj][v];
+                            }
+                        }
+                    }
+            } else {
+                float sacc = 0.f;
+#pragma unroll
+                for (int i = 0; i < WM; ++i)
+#pragma unroll
+                    for (int jj = 0; jj < WN; ++jj)
+#pragma unroll
+                        for (int v = 0; v < 16; ++v) sacc += acc[i][jj][v];
+                if (sacc == 12345.678f) C[t] = sacc;
+            }
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int jj = 0; jj < WN; ++jj)
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) acc[i][jj][v] = 0.f;
+            stage_in_tile = 0; ++jtile;
+        }
+    }
+}
+
+template <int WM, int WN, int WAVES_M, int WAVES_N, int NL, int ABL = 0>
+void run6(const float* A, const float* B, float* C, int M, int N, int K, int nwg = 256) {
+    constexpr int BM = WAVES_M * WM * 32, BN = WAVES_N * WN * 32, NT = (WAVES_M * WAVES_N + NL) * 64;
+    if (N % BN || K % 32) { printf("  v6 tile %3dx%-3d skipped\n", BM, BN); return; }
+    const int tiles = ((M + BM - 1) / BM) * (N / BN);
+    dim3 grid(tiles < nwg ? tiles : nwg);
+    auto go = [&]() { hipLaunchKernelGGL((kt6<WM, WN, WAVES_M, WAVES_N, NL, ABL>), grid, dim3(NT), 0, 0, A, B, C, M, N, K); };
+    hipMemset(C, 0, (size_t)M * N * 4);
+    go(); hipDeviceSynchronize();
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { printf("  launch error %s\n", hipGetErrorString(e)); return; }
+    double md = 0;
+    if (g_ref2) {
+        std::vector<float> c1((size_t)64 * N), c2((size_t)64 * N);
+        for (int part = 0; part < 2; ++part) {
+            const size_t off = part ? (size_t)(M - 64) * N : 0;
+            hipMemcpy(c1.data(), C + off, c1.size() * 4, hipMemcpyDeviceToHost);
+            hipMemcpy(c2.data(), g_ref2 + off, c2.size() * 4, hipMemcpyDeviceToHost);
+            for (size_t i = 0; i < c1.size(); ++i) md = fmax(md, fabs((double)c1[i] - c2[i]));
+        }
+    }
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    float best = 1e9;
+    for (int rr = 0; rr < 6; ++rr) { hipEventRecord(e0); for (int i = 0; i < 10; ++i) go(); hipEventRecord(e1); hipEventSynchronize(e1); float ms; hipEventElapsedTime(&ms, e0, e1); if (ms / 10 < best) best = ms / 10; }
+    printf("  v6 abl %d tile %3dx%-3d consumers %d loaders %d (fp32 operands) grid %5d (tiles %d): %7.1f us  %6.1f TF(f32-eq)  maxdiff %.3g\n", ABL, BM, BN, WAVES_M * WAVES_N, NL, grid.x, tiles, best * 1e3, 2.0 * M * N * K / best / 1e9, md);
+}
+
 static void split_host16(const std::vector<float>& h, size_t rows, int K, std::vector<unsigned short>& out) {
     out.assign(rows * K * 3, 0);
     for (size_t rw = 0; rw < rows; ++rw)
@@ -997,10 +1199,10 @@ int main(int argc, char** argv) {
     runp<2, 3, 2, 2, 1>(C, M, N, K, Ap, Bp);
     runp<2, 3, 2, 2, 3>(C, M, N, K, Ap, Bp);
     runr<2, 3, 2, 2, 4, 0>(C, M, N, K, Ap, Bp);
-    runr<2, 3, 2, 2, 4, 1>(C, M, N, K, Ap, Bp);
-    runs<2, 3, 2, 2, 4, 0>(C, M, N, K, Ap, Bp);
-    runs<2, 3, 2, 2, 4, 1>(C, M, N, K, Ap, Bp);
-    runs<2, 3, 2, 2, 4, 3>(C, M, N, K, Ap, Bp);
-    runs<2, 3, 2, 2, 2, 0>(C, M, N, K, Ap, Bp);
+    run6<2, 3, 2, 2, 8, 0>(A, B, C, M, N, K);
+    run6<2, 3, 2, 2, 8, 16>(A, B, C, M, N, K);
+    run6<2, 3, 2, 2, 8, 17>(A, B, C, M, N, K);
+    run6<2, 3, 2, 2, 8, 21>(A, B, C, M, N, K);
+    run6<2, 3, 2, 2, 8, 5>(A, B, C, M, N, K);
     return 0;
 }
