@@ -66,6 +66,11 @@ __device__ __forceinline__ f32x4 bload4(__amdgpu_buffer_rsrc_t rsrc, unsigned of
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)off, 0, 0));
 }
 
+// same with a wave-uniform byte offset in the SGPR operand (it takes part in the range check: num_records - soffset)
+__device__ __forceinline__ f32x4 bload4s(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, (int)soff, 0));
+}
+
 // ---- global -> register staging ------------------------------------------------------------
 // FAST path: 16-byte hardware-bounds-checked buffer loads.  Each thread's byte offsets into the
 // operand are computed ONCE per output tile (OOB when its row / column is outside the matrix);
