@@ -167,7 +167,7 @@ def bmu_roofline(ops, B, world, bmu_ms, bmu_calls):
                          "frac": round(nbytes / t_s / 1e9 / HBM_PEAK_GBS, 4)}}
 
 
-def launch_ranks(args) -> int:
+def launch_ranks(args, script=None, argv=None) -> int:
     """One child process per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in its environment), rendezvous on
     127.0.0.1.  Rank 0 inherits stdout, so its JSON line is this command's output."""
     import socket
@@ -180,11 +180,30 @@ def launch_ranks(args) -> int:
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+        procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] +
+                                      (sys.argv[1:] if argv is None else list(argv)), env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
+    # a rank that dies must not leave the others waiting in the rendezvous / a collective until their time-out
     rc = 0
-    for p in procs:
-        rc = max(rc, abs(p.wait()))
+    live = list(procs)
+    while live:
+        time.sleep(0.2)
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            rc = max(rc, abs(code))
+        if rc and live:
+            for p in live:                         # exactly the children started above
+                p.terminate()
+            for p in live:
+                try:
+                    p.wait(timeout=20)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+                    p.wait()
+            live = []
     return rc
 
 

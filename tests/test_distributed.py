@@ -150,3 +150,26 @@ def test_two_ranks_equal_single_process_on_concatenated_batch(tmp_path):
     p0 = init.arena.params.cpu()
     assert rel_err(dp["params"] - p0, ref - p0) < 2e-3
     assert torch.allclose(dp["params"], ref, atol=0.25 * dp["lr"])      # within a quarter of one Adam step
+
+
+def test_bench_launcher_stops_the_other_ranks_when_one_dies(tmp_path):
+    """bench.py --gpus N as its own launcher: a rank that exits non-zero ends the job (the others are terminated, not
+    left waiting in the rendezvous) and its code is the launcher's."""
+    import importlib.util
+    import time
+    import types
+    spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(os.path.dirname(__file__), "..", "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    script = tmp_path / "rank.py"
+    script.write_text("import os, sys, time\n"
+                      "assert os.environ['MASTER_ADDR'] == '127.0.0.1' and int(os.environ['MASTER_PORT']) > 0\n"
+                      "assert os.environ['WORLD_SIZE'] == '3' and os.environ['LOCAL_RANK'] == os.environ['RANK']\n"
+                      "if os.environ['RANK'] == '1':\n    sys.exit(3)\n"
+                      "time.sleep(120)\n")
+    t0 = time.time()
+    rc = bench.launch_ranks(types.SimpleNamespace(gpus=3), script=str(script), argv=[])
+    assert rc != 0 and time.time() - t0 < 60
+    ok = tmp_path / "ok.py"
+    ok.write_text("import os\nprint(os.environ['RANK'])\n")
+    assert bench.launch_ranks(types.SimpleNamespace(gpus=2), script=str(ok), argv=[]) == 0
