@@ -8,7 +8,7 @@ for i in $(seq 1 $R); do
   for L in "$A" "$B"; do
     cp "$L" vit_som_amd/libvitsom_hip.so
     echo -n "$(basename $L): "
-    python tools/ab_step.py X=0 15 2 | tail -1
+    python tools/ab_step.py side_stream=1 15 2 | tail -1
   done
 done
 cp "$B" vit_som_amd/libvitsom_hip.so

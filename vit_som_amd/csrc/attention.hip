@@ -18,8 +18,13 @@
 // tokens would cost 800 MFMAs per head for 528 useful and a fifth wave doing 160 MFMAs for ONE
 // valid row.  Instead tokens 1..16m run as m full, unmasked MFMA tiles (m balanced waves) and token
 // 0 is the "extra" row/column: as a key/query it enters every tile wave through two VALU dot
-// products and rank-1 updates of the accumulators; as the wave's own row it is handled by one
-// additional wave with VALU only (lane per key for the dots, lane per channel for the sums).
+// products and rank-1 updates of the accumulators; as a row of its own (its output / its gradients) it
+// is shared out among the tile waves: each covers the 16-token tiles it owns anyway with VALU (4 lanes
+// per token for the dots, lane per channel for the sums), the partial results meet in LDS and wave 0
+// adds them in wave order.  (It used to be a fifth, VALU-only wave.  A 5-wave workgroup puts two waves
+// on one SIMD, and that SIMD's register file then decides the residency of the whole CU: 3 workgroups
+// instead of 4 in the forward, ONE instead of 2 in the fused backward -- measured with
+// tools/attn_lab.hip / tools/occupancy_probe.hip; with 4 waves the LDS footprint is the limit again.)
 #include "common.h"
 
 #include <atomic>
@@ -30,29 +35,85 @@ namespace vsom {
 // test hook (vsom_set_attention_fused): 0 keeps the short-sequence backward as two launches
 static std::atomic<int> g_attn_fused{1};
 
-constexpr int MAXCH = 5;   // EXTRA mode: the VALU wave walks the rows in chunks of 64 -> N <= 320
+// tools/attn_lab.hip builds this file with VSOM_ATTN_STAMPS: thread 0 of every workgroup records the 100 MHz
+// real-time counter at four points (+ the hardware id of its wave); the library build compiles none of it
+#ifdef VSOM_ATTN_STAMPS
+__device__ unsigned long long* g_attn_stamps = nullptr;          // [grid][6]
+#define ATTN_STAMP(i)                                                                              \
+    do {                                                                                           \
+        if (threadIdx.x == 0 && g_attn_stamps) g_attn_stamps[blockIdx.x * 6 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+#define ATTN_STAMP_HWID()                                                                          \
+    do {                                                                                           \
+        if (threadIdx.x == 0 && g_attn_stamps) {                                                   \
+            unsigned hw, xcc;                                                                      \
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));                       \
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));                     \
+            g_attn_stamps[blockIdx.x * 6 + 4] = hw;                                                \
+            g_attn_stamps[blockIdx.x * 6 + 5] = xcc;                                               \
+        }                                                                                          \
+    } while (0)
+#else
+#define ATTN_STAMP(i)
+#define ATTN_STAMP_HWID()
+#endif
 
+
+// LDS image of a [rows, hd] slice: rows padded by 4 floats (row stride = 4 banks mod 64: the fragment reads
+// -- 16 rows x one 16-byte chunk per 16-lane group -- and the accumulate reads -- 4 rows x 16 consecutive
+// floats -- are conflict-free, and every address is affine in (row, col): immediates, no address arithmetic).
+// An unpadded, XOR-swizzled image was measured too (it is the shape a full-wave LDS-DMA load needs): correct
+// and conflict-free as well, but the XOR per access costs VALU in kernels that are VALU-bound (forward
+// 36.0 -> 36.6 us, fused backward 87.5 -> 91.5 us at N = 65).
 template <int HDP>
 struct ACfg {
+    static constexpr bool VEC = (HDP % 16 == 0);  // head dim fully valid, 16-B vector accesses
     static constexpr int S = HDP + 4;             // LDS row stride (floats); 16-B aligned rows
     static constexpr int NMM = HDP / 4;           // MFMAs (4 deep) per score tile
     static constexpr int NDT = (HDP + 15) / 16;   // 16-wide output tiles over the head dim
-    static constexpr bool VEC = (HDP % 16 == 0);  // head dim fully valid, 16-B vector accesses
+    static __device__ __forceinline__ int off(int row, int col) { return row * S + col; }
 };
 
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
+// Cross-lane reductions without the LDS crossbar (ds_bpermute: an LDS instruction and its latency per step; these
+// sit on the kernels' serial chains).  Over the 4 lane groups (l >> 4): v_permlane16_swap / v_permlane32_swap
+// (gfx950) of two copies of v leave the even and the odd partner in the two results; within a group of 16
+// lanes: DPP row rotations.  Every lane of the reduced set ends with the same bits.
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void swap16(float v, float& a, float& b) {
+    const u32x2 t = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    a = __uint_as_float(t[0]); b = __uint_as_float(t[1]);
+}
+__device__ __forceinline__ void swap32(float v, float& a, float& b) {
+    const u32x2 t = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    a = __uint_as_float(t[0]); b = __uint_as_float(t[1]);
+}
 __device__ __forceinline__ float group_sum(float v) {      // over the 4 lane groups (l >> 4)
-    v += __shfl_xor(v, 16, 64);
-    v += __shfl_xor(v, 32, 64);
-    return v;
+    float a, b;
+    swap16(v, a, b); v = a + b;
+    swap32(v, a, b); return a + b;
 }
 __device__ __forceinline__ float group_max(float v) {
-    v = fmaxf(v, __shfl_xor(v, 16, 64));
-    v = fmaxf(v, __shfl_xor(v, 32, 64));
+    float a, b;
+    swap16(v, a, b); v = fmaxf(a, b);
+    swap32(v, a, b); return fmaxf(a, b);
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_row(float v) {        // CTRL 0x120 + n: rotate right by n within each 16 lanes
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float tile_sum(float v) {       // over the 16 lanes of a group (same l >> 4)
+    v += dpp_row<0x128>(v); v += dpp_row<0x124>(v); v += dpp_row<0x122>(v); v += dpp_row<0x121>(v);
     return v;
 }
+__device__ __forceinline__ float tile_max(float v) {
+    v = fmaxf(v, dpp_row<0x128>(v)); v = fmaxf(v, dpp_row<0x124>(v));
+    v = fmaxf(v, dpp_row<0x122>(v)); v = fmaxf(v, dpp_row<0x121>(v));
+    return v;
+}
+__device__ __forceinline__ float wave_sum64(float v) { return group_sum(tile_sum(v)); }
 // token index of row r of tile t
 template <bool EXTRA>
 __device__ __forceinline__ int tok(int t, int r) { return (EXTRA ? 1 : 0) + 16 * t + r; }
@@ -68,7 +129,7 @@ __device__ __forceinline__ void stage_rows(float* lds, const float* __restrict__
             const int row = idx / C4, c4 = idx % C4;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (row < N) v = *reinterpret_cast<const f32x4*>(src + (long)row * rs + 4 * c4);
-            *reinterpret_cast<f32x4*>(lds + row * S + 4 * c4) = v;
+            *reinterpret_cast<f32x4*>(lds + ACfg<HDP>::off(row, 4 * c4)) = v;
         }
     } else {
         for (int idx = threadIdx.x; idx < nrows * HDP; idx += blockDim.x) {
@@ -84,7 +145,7 @@ template <int HDP>
 __device__ __forceinline__ void stage_rows_pair(float* ldsA, const float* __restrict__ srcA, long rsA, float* ldsB,
                                                 const float* __restrict__ srcB, long rsB, int N, int nrows, int hd) {
     if constexpr (ACfg<HDP>::VEC) {
-        constexpr int S = ACfg<HDP>::S, C4 = HDP / 4;
+        constexpr int C4 = HDP / 4;
         const int total = nrows * C4, step = blockDim.x;
         for (int base = threadIdx.x; base < total; base += 4 * step) {
             f32x4 va[4], vb[4];
@@ -102,8 +163,8 @@ __device__ __forceinline__ void stage_rows_pair(float* ldsA, const float* __rest
             for (int u = 0; u < 4; ++u) {
                 const int idx = base + u * step, row = idx / C4, c4 = idx % C4;
                 if (idx < total) {
-                    *reinterpret_cast<f32x4*>(ldsA + row * S + 4 * c4) = va[u];
-                    *reinterpret_cast<f32x4*>(ldsB + row * S + 4 * c4) = vb[u];
+                    *reinterpret_cast<f32x4*>(ldsA + ACfg<HDP>::off(row, 4 * c4)) = va[u];
+                    *reinterpret_cast<f32x4*>(ldsB + ACfg<HDP>::off(row, 4 * c4)) = vb[u];
                 }
             }
         }
@@ -118,7 +179,7 @@ __device__ __forceinline__ void stage_rows_quad(float* l0, const float* __restri
                                                 const float* __restrict__ s1, long r1, float* l2,
                                                 const float* __restrict__ s2, long r2, float* l3,
                                                 const float* __restrict__ s3, long r3, int N, int nrows) {
-    constexpr int S = ACfg<HDP>::S, C4 = HDP / 4;
+    constexpr int C4 = HDP / 4;
     const int total = nrows * C4, step = blockDim.x;
     for (int base = threadIdx.x; base < total; base += 4 * step) {
         f32x4 v[4][4];
@@ -136,10 +197,10 @@ __device__ __forceinline__ void stage_rows_quad(float* l0, const float* __restri
         for (int u = 0; u < 4; ++u) {
             const int idx = base + u * step, row = idx / C4, c4 = idx % C4;
             if (idx < total) {
-                *reinterpret_cast<f32x4*>(l0 + row * S + 4 * c4) = v[0][u];
-                *reinterpret_cast<f32x4*>(l1 + row * S + 4 * c4) = v[1][u];
-                *reinterpret_cast<f32x4*>(l2 + row * S + 4 * c4) = v[2][u];
-                *reinterpret_cast<f32x4*>(l3 + row * S + 4 * c4) = v[3][u];
+                *reinterpret_cast<f32x4*>(l0 + ACfg<HDP>::off(row, 4 * c4)) = v[0][u];
+                *reinterpret_cast<f32x4*>(l1 + ACfg<HDP>::off(row, 4 * c4)) = v[1][u];
+                *reinterpret_cast<f32x4*>(l2 + ACfg<HDP>::off(row, 4 * c4)) = v[2][u];
+                *reinterpret_cast<f32x4*>(l3 + ACfg<HDP>::off(row, 4 * c4)) = v[3][u];
             }
         }
     }
@@ -173,12 +234,27 @@ __device__ __forceinline__ void load_frag(float (&f)[ACfg<HDP>::NMM], const floa
     }
 }
 
+// the same fragment of row `row` of an LDS slice image
+template <int HDP>
+__device__ __forceinline__ void load_frag_lds(float (&f)[ACfg<HDP>::NMM], const float* Y, int row, int qp) {
+    if constexpr (ACfg<HDP>::VEC) {
+#pragma unroll
+        for (int g = 0; g < HDP / 16; ++g) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(Y + ACfg<HDP>::off(row, 16 * g + 4 * qp));
+#pragma unroll
+            for (int s = 0; s < 4; ++s) f[4 * g + s] = v[s];
+        }
+    } else {
+        load_frag<HDP>(f, Y + row * ACfg<HDP>::S, qp, true, HDP);
+    }
+}
+
 // acc[4q'+reg][own row] = sum_d Y[row0 + 4q'+reg][d] * own[row][d]    (row0 = first token of the tile)
 template <int HDP>
 __device__ __forceinline__ f32x4 score_tile(const float* Ylds, int row0, int r, int qp,
                                             const float (&bf)[ACfg<HDP>::NMM]) {
     float af[ACfg<HDP>::NMM];
-    load_frag<HDP>(af, Ylds + (row0 + r) * ACfg<HDP>::S, qp, true, HDP);
+    load_frag_lds<HDP>(af, Ylds, row0 + r, qp);
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int mm = 0; mm < ACfg<HDP>::NMM; ++mm) acc = mfma16(af[mm], bf[mm], acc);
@@ -190,8 +266,8 @@ __device__ __forceinline__ void score_tile2(const float* Y0, int row0, const flo
                                             int row1, const float (&b1)[ACfg<HDP>::NMM], int r, int qp, f32x4& acc0,
                                             f32x4& acc1) {
     float a0[ACfg<HDP>::NMM], a1[ACfg<HDP>::NMM];
-    load_frag<HDP>(a0, Y0 + (row0 + r) * ACfg<HDP>::S, qp, true, HDP);
-    load_frag<HDP>(a1, Y1 + (row1 + r) * ACfg<HDP>::S, qp, true, HDP);
+    load_frag_lds<HDP>(a0, Y0, row0 + r, qp);
+    load_frag_lds<HDP>(a1, Y1, row1 + r, qp);
     acc0 = f32x4{0.f, 0.f, 0.f, 0.f};
     acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -205,13 +281,12 @@ __device__ __forceinline__ void score_tile2(const float* Y0, int row0, const flo
 template <int HDP>
 __device__ __forceinline__ void accum_tile(f32x4 (&o)[ACfg<HDP>::NDT], const float* Zlds, int row0, int r, int qp,
                                            f32x4 p) {
-    constexpr int S = ACfg<HDP>::S;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {                // s outer: the NDT accumulators form independent chains
 #pragma unroll
         for (int dt = 0; dt < ACfg<HDP>::NDT; ++dt) {
             float a = 0.f;
-            if (ACfg<HDP>::VEC || 16 * dt + r < HDP) a = Zlds[(row0 + 4 * qp + s) * S + 16 * dt + r];
+            if (ACfg<HDP>::VEC || 16 * dt + r < HDP) a = Zlds[ACfg<HDP>::off(row0 + 4 * qp + s, 16 * dt + r)];
             o[dt] = mfma16(a, p[s], o[dt]);
         }
     }
@@ -220,15 +295,14 @@ template <int HDP>
 __device__ __forceinline__ void accum_tile2(f32x4 (&o0)[ACfg<HDP>::NDT], const float* Z0, f32x4 p0,
                                             f32x4 (&o1)[ACfg<HDP>::NDT], const float* Z1, f32x4 p1, int row0, int r,
                                             int qp) {
-    constexpr int S = ACfg<HDP>::S;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
 #pragma unroll
         for (int dt = 0; dt < ACfg<HDP>::NDT; ++dt) {
             float a0 = 0.f, a1 = 0.f;
             if (ACfg<HDP>::VEC || 16 * dt + r < HDP) {
-                a0 = Z0[(row0 + 4 * qp + s) * S + 16 * dt + r];
-                a1 = Z1[(row0 + 4 * qp + s) * S + 16 * dt + r];
+                a0 = Z0[ACfg<HDP>::off(row0 + 4 * qp + s, 16 * dt + r)];
+                a1 = Z1[ACfg<HDP>::off(row0 + 4 * qp + s, 16 * dt + r)];
             }
             o0[dt] = mfma16(a0, p0[s], o0[dt]);
             o1[dt] = mfma16(a1, p1[s], o1[dt]);
@@ -281,49 +355,98 @@ __device__ __forceinline__ void axpy_row(f32x4 (&o)[ACfg<HDP>::NDT], float w, co
         o[dt] += w * v;
     }
 }
-// s[c] = x . Y[64c + lane]   (lane per row, rows beyond nrows give 0)
+// ---- token 0 as a row of its own, one 16-token tile at a time (any tile wave) ----------------------
+// dot of ONE vector x[HDP] (in LDS) with each of the 16 rows row0 + r of Y: the result for row r sits on
+// the lanes (r, *).  (x is re-read per tile on purpose: a fragment kept across the tile loop costs 16
+// registers of a kernel whose residency is register-bound.)
 template <int HDP>
-__device__ __forceinline__ void rows_dot(float (&s)[MAXCH], const float* x, const float* Y, int nrows, int lane) {
-    constexpr int S = ACfg<HDP>::S;
+__device__ __forceinline__ float tile_rows_dot(const float* x, const float* Y, int row0, int r, int qp) {
+    float xf[ACfg<HDP>::NMM], y[ACfg<HDP>::NMM];
+    load_frag<HDP>(xf, x, qp, true, HDP);
+    load_frag_lds<HDP>(y, Y, row0 + r, qp);
+    float s = 0.f;
 #pragma unroll
-    for (int c = 0; c < MAXCH; ++c) {
-        float acc = 0.f;
-        const int row = 64 * c + lane;
-        if (64 * c < nrows && row < nrows) {
-#pragma unroll
-            for (int d4 = 0; d4 < HDP / 4; ++d4) {
-                const f32x4 y = *reinterpret_cast<const f32x4*>(Y + row * S + 4 * d4);
-                const f32x4 xv = *reinterpret_cast<const f32x4*>(x + 4 * d4);
-                acc = fmaf(y[0], xv[0], acc); acc = fmaf(y[1], xv[1], acc);
-                acc = fmaf(y[2], xv[2], acc); acc = fmaf(y[3], xv[3], acc);
-            }
+    for (int mm = 0; mm < ACfg<HDP>::NMM; ++mm) s = fmaf(xf[mm], y[mm], s);
+    return group_sum(s);
+}
+// sum_j w_j * Z[row0 + j][lane] over the 16 rows of the tile (w_j lives on lane j; lane = channel < HDP)
+template <int HDP>
+__device__ __forceinline__ float tile_wsum(float w, const float* Z, int row0, int lane) {
+    float acc = 0.f;
+#pragma unroll 4
+    for (int j = 0; j < 16; ++j) {
+        const float wj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(w), j));
+        if (HDP >= 64 || lane < HDP) acc = fmaf(wj, Z[ACfg<HDP>::off(row0 + j, lane)], acc);
+    }
+    return acc;
+}
+// x . y for two [HDP] vectors in LDS, on every lane
+template <int HDP>
+__device__ __forceinline__ float vec_dot(const float* x, const float* y, int lane) {
+    return wave_sum64((HDP >= 64 || lane < HDP) ? x[lane] * y[lane] : 0.f);
+}
+// dQ of token 0, the part over the 16 keys of one tile: w_j = p_0j (dP_0j - D_0) scale, sum_j w_j K_j
+template <int HDP>
+__device__ __forceinline__ float tok0_dq_partial(const float* q0f, const float* do0f, const float* Ks, const float* Vs, int row0, float l0, float D0,
+                                                 float scale, int lane, int r, int qp) {
+    const float sc = tile_rows_dot<HDP>(q0f, Ks, row0, r, qp);
+    const float dp = tile_rows_dot<HDP>(do0f, Vs, row0, r, qp);
+    const float w = __expf(sc * scale - l0) * (dp - D0) * scale;
+    return tile_wsum<HDP>(w, Ks, row0, lane);
+}
+// wave 0: key 0's own term + the partials of the tile waves in wave order -> dqkv row 0 (q slice)
+template <int HDP>
+__device__ __forceinline__ void tok0_dq_combine(const float* q0, const float* do0, const float* k0, const float* v0,
+                                                const float* PA, int pa_stride, int nwaves, float l0, float D0,
+                                                float scale, float* dst, int hd, int lane) {
+    const float s00 = vec_dot<HDP>(q0, k0, lane);
+    const float dp00 = vec_dot<HDP>(do0, v0, lane);
+    const float w00 = __expf(s00 * scale - l0) * (dp00 - D0) * scale;
+    if (HDP >= 64 || lane < HDP) {
+        float g = w00 * k0[lane];
+        for (int w = 0; w < nwaves; ++w) g += PA[w * pa_stride + lane];
+        if (lane < hd) dst[lane] = g;
+    }
+}
+// dK, dV of token 0, the part over the 16 queries of one tile
+template <int HDP>
+__device__ __forceinline__ void tok0_dkv_partial(const float* k0f, const float* v0f, const float* Qs, const float* Ds, const float* Ls, const float* Es,
+                                                 int row0, float scale, int lane, int r, int qp, float& gk, float& gv) {
+    const float sc = tile_rows_dot<HDP>(k0f, Qs, row0, r, qp);
+    const float dp = tile_rows_dot<HDP>(v0f, Ds, row0, r, qp);
+    const float p = __expf(sc * scale - Ls[row0 + r]);
+    const float ds = p * (dp - Es[row0 + r]) * scale;
+    gv += tile_wsum<HDP>(p, Ds, row0, lane);
+    gk += tile_wsum<HDP>(ds, Qs, row0, lane);
+}
+// wave 0: query 0's own term + the partials (PA rows: [gk | gv], HDP each) -> dqkv row 0 (k and v slices)
+template <int HDP>
+__device__ __forceinline__ void tok0_dkv_combine(const float* q0, const float* do0, const float* k0, const float* v0,
+                                                 const float* PA, int pa_stride, int nwaves, float l0, float D0,
+                                                 float scale, float* dk_dst, float* dv_dst, int hd, int lane) {
+    const float s00 = vec_dot<HDP>(q0, k0, lane);
+    const float dp00 = vec_dot<HDP>(do0, v0, lane);
+    const float p00 = __expf(s00 * scale - l0);
+    const float ds00 = p00 * (dp00 - D0) * scale;
+    if (HDP >= 64 || lane < HDP) {
+        float gk = ds00 * q0[lane], gv = p00 * do0[lane];
+        for (int w = 0; w < nwaves; ++w) {
+            gk += PA[w * pa_stride + lane];
+            gv += PA[w * pa_stride + HDP + lane];
         }
-        s[c] = acc;
+        if (lane < hd) {
+            dk_dst[lane] = gk;
+            dv_dst[lane] = gv;
+        }
     }
 }
-// sum_row w[row] * Z[row][d]   (lane per channel d < HDP)
-template <int HDP>
-__device__ __forceinline__ float rows_wsum(const float* w, const float* Z, int nrows, int d) {
-    constexpr int S = ACfg<HDP>::S;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    int row = 0;
-    for (; row + 3 < nrows; row += 4) {
-        const f32x4 wv = *reinterpret_cast<const f32x4*>(w + row);
-        a0 = fmaf(wv[0], Z[(row + 0) * S + d], a0);
-        a1 = fmaf(wv[1], Z[(row + 1) * S + d], a1);
-        a2 = fmaf(wv[2], Z[(row + 2) * S + d], a2);
-        a3 = fmaf(wv[3], Z[(row + 3) * S + d], a3);
-    }
-    for (; row < nrows; ++row) a0 = fmaf(w[row], Z[row * S + d], a0);
-    return (a0 + a1) + (a2 + a3);
-}
-__device__ __forceinline__ void lds_fence_wave() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
-// LDS carve shared by the three kernels
+// LDS carve shared by the three two-slice kernels: two [nrows][S] slices, optional row statistics, the two
+// token-0 vectors of the EXTRA layout, and the tile waves' token-0 partials (`paw` floats per wave)
 template <int HDP, bool EXTRA>
 struct Carve {
     int ntile, nrows, nrp;
-    float *Y0, *Y1, *L0, *L1, *X0, *X1, *W1, *W2;
+    float *Y0, *Y1, *L0, *L1, *X0, *X1, *PA;
     __device__ __forceinline__ Carve(float* smem, int N, bool with_stats) {
         constexpr int S = ACfg<HDP>::S;
         ntile = EXTRA ? (N - 1) >> 4 : (N + 15) >> 4;
@@ -335,18 +458,20 @@ struct Carve {
         L1 = L0 + (with_stats ? nrp : 0);
         X0 = L1 + (with_stats ? nrp : 0);
         X1 = X0 + HDP;
-        W1 = X1 + HDP;
-        W2 = W1 + nrp;
+        PA = X1 + HDP;
     }
 };
 
 // ------------------------------------------------------------------ forward
 template <int HDP, bool EXTRA>
-__global__ __launch_bounds__(576) void attn_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+__global__ __launch_bounds__(512, 4) void attn_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out,
                                                        float* __restrict__ lse, int N, int H, int hd,
                                                        float scale) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int NDT = ACfg<HDP>::NDT;
+    constexpr int NMM = ACfg<HDP>::NMM;
+    constexpr int S = ACfg<HDP>::S;
+    constexpr int PAW = HDP + 2;                   // token-0 partial of a wave: o[HDP], m, l
     const int b = blockIdx.x / H, h = blockIdx.x % H;
     const int E = H * hd, E3 = 3 * E;
     const Carve<HDP, EXTRA> cv(smem, N, false);
@@ -355,41 +480,21 @@ __global__ __launch_bounds__(576) void attn_fwd_kernel(const float* __restrict__
     float* Vs = cv.Y1;
     const float* base = qkv + (long)b * N * E3 + h * hd;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
-    const int tile_waves = nwaves - (EXTRA ? 1 : 0);
-    const bool extra_wave = EXTRA && wave == tile_waves;
     const int r = lane & 15, qp = lane >> 4;
     // the wave's first query fragment is requested BEFORE the K/V staging (latency overlaps it)
-    float qf[ACfg<HDP>::NMM];
-    if (!extra_wave) load_frag<HDP>(qf, base + (long)tok<EXTRA>(wave, r) * E3, qp, tok<EXTRA>(wave, r) < N, hd);
+    float qf[NMM];
+    ATTN_STAMP(0);
+    ATTN_STAMP_HWID();
+    load_frag<HDP>(qf, base + (long)tok<EXTRA>(wave, r) * E3, qp, tok<EXTRA>(wave, r) < N, hd);
     stage_rows_pair<HDP>(Ks, base + E, E3, Vs, base + 2 * E, E3, N, cv.nrows, hd);
     if (EXTRA) stage_vec<HDP>(cv.X0, base, hd);                       // q of token 0
     __syncthreads();
+    ATTN_STAMP(1);
 
-    if (extra_wave) {                                                  // token 0 as a query: VALU only
-        float s[MAXCH];
-        rows_dot<HDP>(s, cv.X0, Ks, N, lane);
-        float m = -INFINITY;
-#pragma unroll
-        for (int c = 0; c < MAXCH; ++c) { s[c] = (64 * c + lane < N) ? s[c] * scale : -INFINITY; m = fmaxf(m, s[c]); }
-        m = wave_max(m);
-        float l = 0.f;
-#pragma unroll
-        for (int c = 0; c < MAXCH; ++c) {
-            const float p = __expf(s[c] - m);
-            l += p;
-            if (64 * c + lane < N) cv.W1[64 * c + lane] = p;
-        }
-        l = wave_sum(l);
-        lds_fence_wave();
-        if (lane < HDP) {
-            const float o = rows_wsum<HDP>(cv.W1, Vs, N, lane) / l;
-            if (lane < hd) out[((long)b * N) * E + h * hd + lane] = o;
-        }
-        if (lane == 0) lse[((long)b * H + h) * N] = m + logf(l);
-        return;
-    }
+    // token 0 as a query: running softmax state over the key tiles this wave owns (lane = channel for x0o)
+    float x0m = -INFINITY, x0l = 0.f, x0o = 0.f;
 
-    for (int qt = wave; qt < ntile; qt += tile_waves) {
+    for (int qt = wave; qt < ntile; qt += nwaves) {
         const int query = tok<EXTRA>(qt, r);
         const bool qok = query < N;
         if (qt != wave) load_frag<HDP>(qf, base + (long)query * E3, qp, qok, hd);
@@ -448,14 +553,49 @@ __global__ __launch_bounds__(576) void attn_fwd_kernel(const float* __restrict__
         const float inv = 1.0f / l;
 #pragma unroll
         for (int dt = 0; dt < NDT; ++dt) o[dt] *= inv;
+        ATTN_STAMP(2);
         store_rows<HDP>(o, out + ((long)b * N + query) * E + h * hd, qp, qok, hd);
         if (qp == 0 && qok) lse[((long)b * H + h) * N + query] = m + logf(l);
+
+        if (EXTRA) {                                                   // token 0 as a query against this tile's 16 keys
+            __builtin_amdgcn_sched_barrier(0);                         // keep its LDS reads out of the tile's register peak
+            const int row0 = tok<EXTRA>(qt, 0);
+            const float sc = tile_rows_dot<HDP>(cv.X0, Ks, row0, r, qp) * scale;
+            const float mnew = fmaxf(x0m, tile_max(sc));
+            const float p = __expf(sc - mnew);
+            const float alpha = __expf(x0m - mnew);
+            x0l = x0l * alpha + tile_sum(p);
+            x0o = x0o * alpha + tile_wsum<HDP>(p, Vs, row0, lane);
+            x0m = mnew;
+        }
     }
+    if (EXTRA) {
+        float* pa = cv.PA + wave * PAW;
+        if (HDP >= 64 || lane < HDP) pa[lane] = x0o;
+        if (lane == 0) { pa[HDP] = x0m; pa[HDP + 1] = x0l; }
+        const float s00 = (wave == 0) ? vec_dot<HDP>(cv.X0, Ks, lane) * scale : 0.f;
+        __syncthreads();
+        if (wave == 0) {                                               // key 0 itself, then the waves in order
+            float m = s00;
+            for (int w = 0; w < nwaves; ++w) m = fmaxf(m, cv.PA[w * PAW + HDP]);
+            float l = __expf(s00 - m);
+            float o = (HDP >= 64 || lane < HDP) ? l * Vs[lane] : 0.f;
+            for (int w = 0; w < nwaves; ++w) {
+                const float a = __expf(cv.PA[w * PAW + HDP] - m);
+                l = fmaf(cv.PA[w * PAW + HDP + 1], a, l);
+                if (HDP >= 64 || lane < HDP) o = fmaf(cv.PA[w * PAW + lane], a, o);
+            }
+            if (lane < hd) out[((long)b * N) * E + h * hd + lane] = o / l;
+            if (lane == 0) lse[((long)b * H + h) * N] = m + logf(l);
+        }
+    }
+    ATTN_STAMP(3);
+    (void)S;
 }
 
 // ------------------------------------------------------------------ backward: dQ (+ D = rowsum(dO * O))
 template <int HDP, bool EXTRA>
-__global__ __launch_bounds__(576) void attn_bwd_dq_kernel(const float* __restrict__ qkv,
+__global__ __launch_bounds__(512) void attn_bwd_dq_kernel(const float* __restrict__ qkv,
                                                           const float* __restrict__ out,
                                                           const float* __restrict__ dout,
                                                           const float* __restrict__ lse,
@@ -472,18 +612,22 @@ __global__ __launch_bounds__(576) void attn_bwd_dq_kernel(const float* __restric
     float* Vs = cv.Y1;
     const float* base = qkv + (long)b * N * E3 + h * hd;
     const long obase = (long)b * N * E + h * hd;
+    const long srow0 = ((long)b * H + h) * N;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
-    const int tile_waves = nwaves - (EXTRA ? 1 : 0);
-    const bool extra_wave = EXTRA && wave == tile_waves;
     const int r = lane & 15, qp = lane >> 4;
     float qf[NMM], dof[NMM], of[NMM];
     float lq_first = 0.f;                          // log-sum-exp of the wave's first query row, requested with the fragments
-    if (!extra_wave) {
+    {
         const int q0 = tok<EXTRA>(wave, r);
         load_frag<HDP>(qf, base + (long)q0 * E3, qp, q0 < N, hd);
         load_frag<HDP>(dof, dout + obase + (long)q0 * E, qp, q0 < N, hd);
         load_frag<HDP>(of, out + obase + (long)q0 * E, qp, q0 < N, hd);
-        if (q0 < N) lq_first = lse[((long)b * H + h) * N + q0];
+        if (q0 < N) lq_first = lse[srow0 + q0];
+    }
+    float o0 = 0.f, l0 = 0.f;                      // token 0: its output row (for D_0) and log-sum-exp
+    if (EXTRA) {
+        if (lane < hd) o0 = out[obase + lane];
+        l0 = lse[srow0];
     }
     stage_rows_pair<HDP>(Ks, base + E, E3, Vs, base + 2 * E, E3, N, cv.nrows, hd);
     if (EXTRA) {
@@ -492,31 +636,13 @@ __global__ __launch_bounds__(576) void attn_bwd_dq_kernel(const float* __restric
     }
     __syncthreads();
 
-    if (extra_wave) {                                                  // dQ of token 0: VALU only
-        float d0 = (lane < hd) ? cv.X1[lane] * out[obase + lane] : 0.f;
-        const float D0 = wave_sum(d0);
-        const long srow = ((long)b * H + h) * N;
-        if (lane == 0) delta[srow] = D0;
-        const float l0 = lse[srow];
-        float s[MAXCH], dp[MAXCH];
-        rows_dot<HDP>(s, cv.X0, Ks, N, lane);
-        rows_dot<HDP>(dp, cv.X1, Vs, N, lane);
-#pragma unroll
-        for (int c = 0; c < MAXCH; ++c) {
-            if (64 * c + lane < N) {
-                const float p = __expf(s[c] * scale - l0);
-                cv.W1[64 * c + lane] = p * (dp[c] - D0) * scale;
-            }
-        }
-        lds_fence_wave();
-        if (lane < HDP) {
-            const float g = rows_wsum<HDP>(cv.W1, Ks, N, lane);
-            if (lane < hd) dqkv[(long)b * N * E3 + h * hd + lane] = g;
-        }
-        return;
+    float D0 = 0.f, gq0 = 0.f;
+    if (EXTRA) {
+        D0 = wave_sum64((HDP >= 64 || lane < HDP) ? cv.X1[lane] * o0 : 0.f);
+        if (wave == 0 && lane == 0) delta[srow0] = D0;
     }
 
-    for (int qt = wave; qt < ntile; qt += tile_waves) {
+    for (int qt = wave; qt < ntile; qt += nwaves) {
         const int query = tok<EXTRA>(qt, r);
         const bool qok = query < N;
         if (qt != wave) {
@@ -528,7 +654,7 @@ __global__ __launch_bounds__(576) void attn_bwd_dq_kernel(const float* __restric
 #pragma unroll
         for (int mm = 0; mm < NMM; ++mm) D = fmaf(dof[mm], of[mm], D);
         D = group_sum(D);
-        const long srow = ((long)b * H + h) * N + query;
+        const long srow = srow0 + query;
         if (qp == 0 && qok) delta[srow] = D;
         const float lq = (qt == wave) ? lq_first : (qok ? lse[srow] : 0.f);
         f32x4 dq[NDT];
@@ -553,12 +679,20 @@ __global__ __launch_bounds__(576) void attn_bwd_dq_kernel(const float* __restric
             accum_tile<HDP>(dq, Ks, tok<EXTRA>(t, 0), r, qp, ds);
         }
         store_rows<HDP>(dq, dqkv + ((long)b * N + query) * E3 + h * hd, qp, qok, hd);
+        if (EXTRA) gq0 += tok0_dq_partial<HDP>(cv.X0, cv.X1, Ks, Vs, tok<EXTRA>(qt, 0), l0, D0, scale, lane, r, qp);
+    }
+    if (EXTRA) {
+        if (HDP >= 64 || lane < HDP) cv.PA[wave * HDP + lane] = gq0;
+        __syncthreads();
+        if (wave == 0)
+            tok0_dq_combine<HDP>(cv.X0, cv.X1, Ks, Vs, cv.PA, HDP, nwaves, l0, D0, scale,
+                                 dqkv + (long)b * N * E3 + h * hd, hd, lane);
     }
 }
 
 // ------------------------------------------------------------------ backward: dK, dV
 template <int HDP, bool EXTRA>
-__global__ __launch_bounds__(576) void attn_bwd_dkv_kernel(const float* __restrict__ qkv,
+__global__ __launch_bounds__(512) void attn_bwd_dkv_kernel(const float* __restrict__ qkv,
                                                            const float* __restrict__ dout,
                                                            const float* __restrict__ lse,
                                                            const float* __restrict__ delta,
@@ -577,17 +711,15 @@ __global__ __launch_bounds__(576) void attn_bwd_dkv_kernel(const float* __restri
     float* Es = cv.L1;
     const float* base = qkv + (long)b * N * E3 + h * hd;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
-    const int tile_waves = nwaves - (EXTRA ? 1 : 0);
-    const bool extra_wave = EXTRA && wave == tile_waves;
     const int r = lane & 15, qp = lane >> 4;
     float kf[NMM], vf[NMM];
-    if (!extra_wave) {
+    {
         const int k0 = tok<EXTRA>(wave, r);
         load_frag<HDP>(kf, base + (long)k0 * E3 + E, qp, k0 < N, hd);
         load_frag<HDP>(vf, base + (long)k0 * E3 + 2 * E, qp, k0 < N, hd);
     }
     // row statistics: the first blockDim rows are requested before the slice staging (one exposed
-    // global latency less), the rest (N > blockDim never happens for the supported shapes) after
+    // global latency less), the rest after
     const int i0 = threadIdx.x;
     float l_r = 0.f, e_r = 0.f;
     if (i0 < N) {
@@ -607,33 +739,9 @@ __global__ __launch_bounds__(576) void attn_bwd_dkv_kernel(const float* __restri
     }
     __syncthreads();
 
-    if (extra_wave) {                                                  // dK, dV of token 0: VALU only
-        float s[MAXCH], dp[MAXCH];
-        rows_dot<HDP>(s, cv.X0, Qs, N, lane);                          // s_j = q_j . k_0
-        rows_dot<HDP>(dp, cv.X1, Ds, N, lane);                         // dp_j = dO_j . v_0
-#pragma unroll
-        for (int c = 0; c < MAXCH; ++c) {
-            const int j = 64 * c + lane;
-            if (j < N) {
-                const float p = __expf(s[c] * scale - Ls[j]);
-                cv.W1[j] = p;
-                cv.W2[j] = p * (dp[c] - Es[j]) * scale;
-            }
-        }
-        lds_fence_wave();
-        if (lane < HDP) {
-            const float gv = rows_wsum<HDP>(cv.W1, Ds, N, lane);
-            const float gk = rows_wsum<HDP>(cv.W2, Qs, N, lane);
-            if (lane < hd) {
-                float* drow = dqkv + (long)b * N * E3 + h * hd;
-                drow[E + lane] = gk;
-                drow[2 * E + lane] = gv;
-            }
-        }
-        return;
-    }
+    float gk0 = 0.f, gv0 = 0.f;
 
-    for (int kt = wave; kt < ntile; kt += tile_waves) {
+    for (int kt = wave; kt < ntile; kt += nwaves) {
         const int key = tok<EXTRA>(kt, r);
         const bool kok = key < N;
         if (kt != wave) {
@@ -665,18 +773,31 @@ __global__ __launch_bounds__(576) void attn_bwd_dkv_kernel(const float* __restri
         float* drow = dqkv + ((long)b * N + key) * E3 + h * hd;
         store_rows<HDP>(dk, drow + E, qp, kok, hd);
         store_rows<HDP>(dv, drow + 2 * E, qp, kok, hd);
+        if (EXTRA) tok0_dkv_partial<HDP>(cv.X0, cv.X1, Qs, Ds, Ls, Es, tok<EXTRA>(kt, 0), scale, lane, r, qp, gk0, gv0);
+    }
+    if (EXTRA) {
+        if (HDP >= 64 || lane < HDP) {
+            cv.PA[wave * 2 * HDP + lane] = gk0;
+            cv.PA[wave * 2 * HDP + HDP + lane] = gv0;
+        }
+        __syncthreads();
+        if (wave == 0) {
+            float* drow = dqkv + (long)b * N * E3 + h * hd;
+            tok0_dkv_combine<HDP>(Qs, Ds, cv.X0, cv.X1, cv.PA, 2 * HDP, nwaves, Ls[0], Es[0], scale, drow + E,
+                                  drow + 2 * E, hd, lane);
+        }
     }
 }
 
 // ------------------------------------------------------------------ backward, fused (short sequences)
 // dQ and dK/dV in ONE launch when all four slices (K, V, Q, dO) of an (image, head) fit in LDS next to
-// each other (N = 65, hd = 64: 72 KB): the slices are staged once, D = rowsum(dO * O) goes from the dQ
-// phase to the dK/dV phase through LDS, and the second kernel's launch, staging and prologue
+// each other twice per CU (N = 65, hd = 64: 74 KB): the slices are staged once, D = rowsum(dO * O) goes
+// from the dQ phase to the dK/dV phase through LDS, and the second kernel's launch, staging and prologue
 // disappear.  Phase 1 is attn_bwd_dq_kernel's body (waves own query tiles), phase 2
-// attn_bwd_dkv_kernel's (waves own key tiles); the token-0 vectors of the EXTRA path are row 0 of the
-// staged slices.
+// attn_bwd_dkv_kernel's (waves own key tiles), with the same arithmetic in the same order (the two
+// forms give identical bits); the token-0 vectors of the EXTRA path are row 0 of the staged slices.
 template <int HDP, bool EXTRA>
-__global__ __launch_bounds__(576) void attn_bwd_fused_kernel(const float* __restrict__ qkv, const float* __restrict__ out,
+__global__ __launch_bounds__(512) void attn_bwd_fused_kernel(const float* __restrict__ qkv, const float* __restrict__ out,
                                                              const float* __restrict__ dout, const float* __restrict__ lse,
                                                              float* __restrict__ dqkv, float* __restrict__ delta, int N,
                                                              int H, int hd, float scale) {
@@ -695,22 +816,23 @@ __global__ __launch_bounds__(576) void attn_bwd_fused_kernel(const float* __rest
     float* Ds = Qs + nrows * S;
     float* Ls = Ds + nrows * S;
     float* Es = Ls + nrp;
-    float* W1 = Es + nrp;
-    float* W2 = W1 + nrp;
+    float* PA = Es + nrp;                                              // [nwaves][3 HDP]: gq | gk | gv of token 0
     const float* base = qkv + (long)b * N * E3 + h * hd;
     const long obase = (long)b * N * E + h * hd;
     const long srow0 = ((long)b * H + h) * N;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
-    const int tile_waves = nwaves - (EXTRA ? 1 : 0);
-    const bool extra_wave = EXTRA && wave == tile_waves;
     const int r = lane & 15, qp = lane >> 4;
     float qf[NMM], dof[NMM], of[NMM];
-    if (!extra_wave) {
+    ATTN_STAMP(0);
+    ATTN_STAMP_HWID();
+    {
         const int q0 = tok<EXTRA>(wave, r);
         load_frag<HDP>(qf, base + (long)q0 * E3, qp, q0 < N, hd);
         load_frag<HDP>(dof, dout + obase + (long)q0 * E, qp, q0 < N, hd);
         load_frag<HDP>(of, out + obase + (long)q0 * E, qp, q0 < N, hd);
     }
+    float o0 = 0.f;
+    if (EXTRA && lane < hd) o0 = out[obase + lane];
     float l_r = 0.f;
     if ((int)threadIdx.x < N) l_r = lse[srow0 + threadIdx.x];
     stage_rows_quad<HDP>(Ks, base + E, E3, Vs, base + 2 * E, E3, Qs, base, E3, Ds, dout + obase, E, N, nrows);
@@ -719,105 +841,67 @@ __global__ __launch_bounds__(576) void attn_bwd_fused_kernel(const float* __rest
         Es[i] = 0.f;
     }
     __syncthreads();
+    ATTN_STAMP(1);
 
     // ---- phase 1: dQ and D
-    if (extra_wave) {                                                  // token 0 as a query: VALU only
-        const float* q0v = Qs;                                         // row 0 of the staged slices
-        const float* do0 = Ds;
-        float d0 = (lane < hd) ? do0[lane] * out[obase + lane] : 0.f;
-        const float D0 = wave_sum(d0);
-        if (lane == 0) { delta[srow0] = D0; Es[0] = D0; }
-        const float l0 = Ls[0];
-        float sc[MAXCH], dp[MAXCH];
-        rows_dot<HDP>(sc, q0v, Ks, N, lane);
-        rows_dot<HDP>(dp, do0, Vs, N, lane);
-#pragma unroll
-        for (int c = 0; c < MAXCH; ++c) {
-            if (64 * c + lane < N) {
-                const float p = __expf(sc[c] * scale - l0);
-                W1[64 * c + lane] = p * (dp[c] - D0) * scale;
-            }
-        }
-        lds_fence_wave();
-        if (lane < HDP) {
-            const float gq = rows_wsum<HDP>(W1, Ks, N, lane);
-            if (lane < hd) dqkv[(long)b * N * E3 + h * hd + lane] = gq;
-        }
-    } else {
-        for (int qt = wave; qt < ntile; qt += tile_waves) {
-            const int query = tok<EXTRA>(qt, r);
-            const bool qok = query < N;
-            if (qt != wave) {
-                load_frag<HDP>(qf, base + (long)query * E3, qp, qok, hd);
-                load_frag<HDP>(dof, dout + obase + (long)query * E, qp, qok, hd);
-                load_frag<HDP>(of, out + obase + (long)query * E, qp, qok, hd);
-            }
-            float D = 0.f;
-#pragma unroll
-            for (int mm = 0; mm < NMM; ++mm) D = fmaf(dof[mm], of[mm], D);
-            D = group_sum(D);
-            if (qp == 0 && qok) { delta[srow0 + query] = D; Es[query] = D; }
-            const float lq = qok ? Ls[query] : 0.f;
-            f32x4 dq[NDT];
-#pragma unroll
-            for (int dt = 0; dt < NDT; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (EXTRA) {                                               // token 0 as a key
-                const float s0 = frag_dot_row<HDP>(qf, Ks, qp) * scale;
-                const float dp0 = frag_dot_row<HDP>(dof, Vs, qp);
-                const float p0 = __expf(s0 - lq);
-                axpy_row<HDP>(dq, p0 * (dp0 - D) * scale, Ks, qp);
-            }
-            for (int t = 0; t < ntile; ++t) {
-                f32x4 sc, dp;
-                score_tile2<HDP>(Ks, tok<EXTRA>(t, 0), qf, Vs, tok<EXTRA>(t, 0), dof, r, qp, sc, dp);
-                f32x4 ds;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int key = tok<EXTRA>(t, 4 * qp + e);
-                    const float p = (EXTRA || (key < N && qok)) ? __expf(sc[e] * scale - lq) : 0.f;
-                    ds[e] = p * (dp[e] - D) * scale;
-                }
-                accum_tile<HDP>(dq, Ks, tok<EXTRA>(t, 0), r, qp, ds);
-            }
-            store_rows<HDP>(dq, dqkv + ((long)b * N + query) * E3 + h * hd, qp, qok, hd);
-        }
+    float D0 = 0.f, l0 = 0.f, gq0 = 0.f;
+    if (EXTRA) {                                                       // token 0's vectors are row 0 of the staged slices
+        D0 = wave_sum64((HDP >= 64 || lane < HDP) ? Ds[lane] * o0 : 0.f);
+        l0 = Ls[0];
+        if (wave == 0 && lane == 0) { delta[srow0] = D0; Es[0] = D0; }
     }
-    __syncthreads();                                                   // Es (D of every row) complete; W1 free again
+    for (int qt = wave; qt < ntile; qt += nwaves) {
+        const int query = tok<EXTRA>(qt, r);
+        const bool qok = query < N;
+        if (qt != wave) {
+            load_frag<HDP>(qf, base + (long)query * E3, qp, qok, hd);
+            load_frag<HDP>(dof, dout + obase + (long)query * E, qp, qok, hd);
+            load_frag<HDP>(of, out + obase + (long)query * E, qp, qok, hd);
+        }
+        float D = 0.f;
+#pragma unroll
+        for (int mm = 0; mm < NMM; ++mm) D = fmaf(dof[mm], of[mm], D);
+        D = group_sum(D);
+        if (qp == 0 && qok) { delta[srow0 + query] = D; Es[query] = D; }
+        const float lq = qok ? Ls[query] : 0.f;
+        f32x4 dq[NDT];
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (EXTRA) {                                                   // token 0 as a key
+            const float s0 = frag_dot_row<HDP>(qf, Ks, qp) * scale;
+            const float dp0 = frag_dot_row<HDP>(dof, Vs, qp);
+            const float p0 = __expf(s0 - lq);
+            axpy_row<HDP>(dq, p0 * (dp0 - D) * scale, Ks, qp);
+        }
+        for (int t = 0; t < ntile; ++t) {
+            f32x4 sc, dp;
+            score_tile2<HDP>(Ks, tok<EXTRA>(t, 0), qf, Vs, tok<EXTRA>(t, 0), dof, r, qp, sc, dp);
+            f32x4 ds;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int key = tok<EXTRA>(t, 4 * qp + e);
+                const float p = (EXTRA || (key < N && qok)) ? __expf(sc[e] * scale - lq) : 0.f;
+                ds[e] = p * (dp[e] - D) * scale;
+            }
+            accum_tile<HDP>(dq, Ks, tok<EXTRA>(t, 0), r, qp, ds);
+        }
+        store_rows<HDP>(dq, dqkv + ((long)b * N + query) * E3 + h * hd, qp, qok, hd);
+        if (EXTRA) gq0 += tok0_dq_partial<HDP>(Qs, Ds, Ks, Vs, tok<EXTRA>(qt, 0), l0, D0, scale, lane, r, qp);
+    }
+    if (EXTRA && (HDP >= 64 || lane < HDP)) PA[wave * 3 * HDP + lane] = gq0;
+    __syncthreads();                                                   // Es (D of every row) and the dQ partials complete
+    ATTN_STAMP(2);
 
     // ---- phase 2: dK, dV
-    if (extra_wave) {                                                  // token 0 as a key: VALU only
-        const float* k0v = Ks;
-        const float* v0v = Vs;
-        float sc[MAXCH], dp[MAXCH];
-        rows_dot<HDP>(sc, k0v, Qs, N, lane);                           // s_j = q_j . k_0
-        rows_dot<HDP>(dp, v0v, Ds, N, lane);                           // dp_j = dO_j . v_0
-#pragma unroll
-        for (int c = 0; c < MAXCH; ++c) {
-            const int j = 64 * c + lane;
-            if (j < N) {
-                const float p = __expf(sc[c] * scale - Ls[j]);
-                W1[j] = p;
-                W2[j] = p * (dp[c] - Es[j]) * scale;
-            }
-        }
-        lds_fence_wave();
-        if (lane < HDP) {
-            const float gv = rows_wsum<HDP>(W1, Ds, N, lane);
-            const float gk = rows_wsum<HDP>(W2, Qs, N, lane);
-            if (lane < hd) {
-                float* drow = dqkv + (long)b * N * E3 + h * hd;
-                drow[E + lane] = gk;
-                drow[2 * E + lane] = gv;
-            }
-        }
-        return;
-    }
-    for (int kt = wave; kt < ntile; kt += tile_waves) {
+    float gk0 = 0.f, gv0 = 0.f;
+    if (EXTRA && wave == 0)
+        tok0_dq_combine<HDP>(Qs, Ds, Ks, Vs, PA, 3 * HDP, nwaves, l0, D0, scale, dqkv + (long)b * N * E3 + h * hd, hd, lane);
+    for (int kt = wave; kt < ntile; kt += nwaves) {
         const int key = tok<EXTRA>(kt, r);
         const bool kok = key < N;
         float kf[NMM], vf[NMM];
-        load_frag<HDP>(kf, Ks + (long)(kok ? key : 0) * S, qp, kok, HDP);      // own rows from the staged slices
-        load_frag<HDP>(vf, Vs + (long)(kok ? key : 0) * S, qp, kok, HDP);
+        load_frag_lds<HDP>(kf, Ks, key, qp);                           // own rows from the staged slices (rows N .. nrows-1
+        load_frag_lds<HDP>(vf, Vs, key, qp);                           // of the padded layout are staged as zeros)
         f32x4 dk[NDT], dv[NDT];
 #pragma unroll
         for (int dt = 0; dt < NDT; ++dt) { dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
@@ -843,16 +927,30 @@ __global__ __launch_bounds__(576) void attn_bwd_fused_kernel(const float* __rest
         float* drow = dqkv + ((long)b * N + key) * E3 + h * hd;
         store_rows<HDP>(dk, drow + E, qp, kok, hd);
         store_rows<HDP>(dv, drow + 2 * E, qp, kok, hd);
+        if (EXTRA) tok0_dkv_partial<HDP>(Ks, Vs, Qs, Ds, Ls, Es, tok<EXTRA>(kt, 0), scale, lane, r, qp, gk0, gv0);
     }
+    if (EXTRA) {
+        if (HDP >= 64 || lane < HDP) {
+            PA[wave * 3 * HDP + HDP + lane] = gk0;
+            PA[wave * 3 * HDP + 2 * HDP + lane] = gv0;
+        }
+        __syncthreads();
+        if (wave == 0) {
+            float* drow = dqkv + (long)b * N * E3 + h * hd;
+            tok0_dkv_combine<HDP>(Qs, Ds, Ks, Vs, PA + HDP, 3 * HDP, nwaves, Ls[0], Es[0], scale, drow + E, drow + 2 * E, hd,
+                                  lane);
+        }
+    }
+    ATTN_STAMP(3);
 }
 
 // ------------------------------------------------------------------ host side
 // (A persistent variant -- workgroups looping over (image, head) items with register prefetch of
-// the next item's rows -- was measured and rejected: the extra registers drop residency from 3-4 to
-// 2 workgroups per CU and N = 65 got slower, 42 -> 55 us per forward layer.)
-static bool use_extra(int N) { return N >= 17 && (N % 16) == 1 && N <= 64 * MAXCH; }
+// the next item's rows -- was measured and rejected: the extra registers drop residency and N = 65 got
+// slower, 42 -> 55 us per forward layer.)
+static bool use_extra(int N) { return N >= 17 && (N % 16) == 1; }
 static int attn_tiles(int N) { return use_extra(N) ? (N - 1) / 16 : cdiv(N, 16); }
-static int attn_waves(int N) {          // MFMA (tile) waves; EXTRA mode adds one VALU wave
+static int attn_waves(int N) {          // every wave is an MFMA (tile) wave: at most 8, balanced over the rounds
     const int ntile = attn_tiles(N);
     const int rounds = cdiv(ntile, 8);
     return cdiv(ntile, rounds);
@@ -863,30 +961,31 @@ static int attn_hdp(int hd) {
     if (hd <= 8) return 8;
     return 0;
 }
-static size_t attn_lds_bytes(int N, int hdp, bool with_stats) {
+// paw = token-0 partial floats per wave: forward hdp + 2, dQ hdp, dK/dV 2 hdp
+static int attn_stride(int hdp) { return hdp + 4; }        // ACfg<HDP>::S
+static size_t attn_lds_bytes(int N, int hdp, bool with_stats, int paw) {
     const int nrows = use_extra(N) ? N : cdiv(N, 16) * 16;
     const int nrp = (nrows + 3) & ~3;
-    return ((size_t)2 * nrows * (hdp + 4) + (with_stats ? 2 * nrp : 0) + 2 * hdp + 2 * nrp) * sizeof(float);
+    return ((size_t)2 * nrows * attn_stride(hdp) + (with_stats ? 2 * nrp : 0) + 2 * hdp + (size_t)attn_waves(N) * paw) * sizeof(float);
 }
-
 static size_t attn_fused_lds_bytes(int N, int hdp) {
     const int nrows = use_extra(N) ? N : cdiv(N, 16) * 16;
     const int nrp = (nrows + 3) & ~3;
-    return ((size_t)4 * nrows * (hdp + 4) + 4 * nrp) * sizeof(float);
+    return ((size_t)4 * nrows * attn_stride(hdp) + 2 * nrp + (size_t)attn_waves(N) * 3 * hdp) * sizeof(float);
 }
 
 template <int HDP, bool EXTRA>
 static int launch_fwd_t(const float* qkv, float* out, float* lse, int B, int N, int H, int hd, hipStream_t st) {
-    const size_t lds = attn_lds_bytes(N, HDP, false);
-    hipLaunchKernelGGL((attn_fwd_kernel<HDP, EXTRA>), dim3(B * H), dim3(64 * (attn_waves(N) + (EXTRA ? 1 : 0))), lds, st, qkv,
-                       out, lse, N, H, hd, 1.0f / sqrtf((float)hd));
+    const size_t lds = attn_lds_bytes(N, HDP, false, HDP + 2);
+    hipLaunchKernelGGL((attn_fwd_kernel<HDP, EXTRA>), dim3(B * H), dim3(64 * attn_waves(N)), lds, st, qkv, out, lse, N, H, hd,
+                       1.0f / sqrtf((float)hd));
     VSOM_LAUNCH_CHECK("attn_fwd_kernel");
 }
 template <int HDP, bool EXTRA>
 static int launch_bwd_t(const float* qkv, const float* out, const float* dout, const float* lse, float* dqkv,
                         float* delta, int B, int N, int H, int hd, hipStream_t st) {
     const float scale = 1.0f / sqrtf((float)hd);
-    const dim3 block(64 * (attn_waves(N) + (EXTRA ? 1 : 0)));
+    const dim3 block(64 * attn_waves(N));
     // all four slices in LDS and still two workgroups per CU -> one fused launch (vector path only)
     const size_t fused_lds = attn_fused_lds_bytes(N, HDP);
     if (ACfg<HDP>::VEC && fused_lds <= 80 * 1024 && g_attn_fused.load(std::memory_order_relaxed)) {
@@ -894,12 +993,12 @@ static int launch_bwd_t(const float* qkv, const float* out, const float* dout, c
                            delta, N, H, hd, scale);
         VSOM_LAUNCH_CHECK("attn_bwd_fused_kernel");
     }
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<HDP, EXTRA>), dim3(B * H), block, attn_lds_bytes(N, HDP, false), st, qkv, out, dout,
-                       lse, dqkv, delta, N, H, hd, scale);
+    hipLaunchKernelGGL((attn_bwd_dq_kernel<HDP, EXTRA>), dim3(B * H), block, attn_lds_bytes(N, HDP, false, HDP), st, qkv, out,
+                       dout, lse, dqkv, delta, N, H, hd, scale);
     int rc = hip_status(hipGetLastError(), "attn_bwd_dq_kernel");
     if (rc) return rc;
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<HDP, EXTRA>), dim3(B * H), block, attn_lds_bytes(N, HDP, true), st, qkv, dout, lse,
-                       delta, dqkv, N, H, hd, scale);
+    hipLaunchKernelGGL((attn_bwd_dkv_kernel<HDP, EXTRA>), dim3(B * H), block, attn_lds_bytes(N, HDP, true, 2 * HDP), st, qkv,
+                       dout, lse, delta, dqkv, N, H, hd, scale);
     VSOM_LAUNCH_CHECK("attn_bwd_dkv_kernel");
 }
 template <int HDP>
@@ -918,8 +1017,8 @@ static int attn_check(const char* who, int B, int N, int H, int hd, int* hdp) {
     VSOM_REQUIRE(B > 0 && N > 0 && H > 0 && hd > 0, VSOM_EINVAL, "%s: bad shape B=%d N=%d H=%d hd=%d", who, B, N, H, hd);
     *hdp = attn_hdp(hd);
     VSOM_REQUIRE(*hdp != 0, VSOM_EUNSUPPORTED, "%s: head dim %d not supported (1..8, 16, 32, 64)", who, hd);
-    VSOM_REQUIRE(attn_lds_bytes(N, *hdp, true) <= 160 * 1024, VSOM_EUNSUPPORTED,
-                 "%s: N=%d hd=%d needs %zu B of LDS (> 160 KiB)", who, N, hd, attn_lds_bytes(N, *hdp, true));
+    VSOM_REQUIRE(attn_lds_bytes(N, *hdp, true, 2 * *hdp) <= 160 * 1024, VSOM_EUNSUPPORTED,
+                 "%s: N=%d hd=%d needs %zu B of LDS (> 160 KiB)", who, N, hd, attn_lds_bytes(N, *hdp, true, 2 * *hdp));
     return VSOM_OK;
 }
 
