@@ -41,8 +41,10 @@ static void probe(int threads, int lds_bytes) {
     for (auto v : h) t0 = v < t0 ? v : t0;
     int first = 0;
     for (auto v : h) first += (v - t0) < 1000;              // started within 10 us
-    printf("VGPR-ish %3d  threads %3d  LDS %6.1f KB : %4d of %d workgroups resident at once = %.2f per CU  (%s)\n", VG, threads,
-           lds_bytes / 1024.0, first, grid, first / 256.0, hipGetErrorString(e));
+    hipFuncAttributes fa;
+    hipFuncGetAttributes(&fa, (const void*)spin<VG>);
+    printf("VGPRs %3d  threads %3d (%d waves)  LDS %6.1f KB : %4d of %d workgroups resident at once = %.2f per CU  (%s)\n", fa.numRegs,
+           threads, threads / 64, lds_bytes / 1024.0, first, grid, first / 256.0, hipGetErrorString(e));
     hipFree(st);
     hipFree(sink);
 }
@@ -51,5 +53,9 @@ int main() {
     for (int kb : {16, 32, 36, 40, 48, 53, 56, 64, 72, 76, 80, 96, 128, 160}) probe<16>(320, kb * 1024 - (kb == 160 ? 0 : 0));
     for (int kb : {36, 72}) probe<16>(256, kb * 1024);
     for (int kb : {36, 72}) probe<100>(320, kb * 1024);
+    // the same register budget with 3-, 4-, 5-, 6- and 8-wave workgroups (LDS small): which SIMD fills first?
+    for (int th : {192, 256, 320, 384, 512}) probe<60>(th, 4096);
+    for (int th : {192, 256, 320, 384, 512}) probe<100>(th, 4096);
+    for (int th : {192, 256, 320, 384, 512}) probe<150>(th, 4096);
     return 0;
 }
