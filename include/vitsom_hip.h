@@ -265,8 +265,9 @@ int vsom_bmu_cosine_x3_finalize(const float* X, long ldx, const float* W, const 
 
 /* ------------------------------------------------------------------ small utilities */
 int vsom_fill(float* p, long n, float value, vsom_stream_t stream);
-/* out[0] = ca * a[0] + cb * b[0]: the step's total loss from its two device-side sums (vit_som.py:93,98) */
-int vsom_lincomb2(float* out, const float* a, float ca, const float* b, float cb, vsom_stream_t stream);
+/* out[0] = ca * a[0] + cb * b[0]: the step's total loss from its two device-side sums (vit_som.py:93,98); `counter`
+   (nullable, one int64 on the device) is incremented by 1 in the same launch: `self.iteration += 1` (vit_som.py:104) */
+int vsom_lincomb2(float* out, const float* a, float ca, const float* b, float cb, int64_t* counter, vsom_stream_t stream);
 /* out[i] = factor * (*scale_dev) * a[i] * b[i]  (b, scale_dev nullable -> 1): the elementwise products autograd needs
    for mean(weights * distances) (som_layer.py:137-142) with the upstream gradient as a device scalar */
 int vsom_scaled_mul(float* out, const float* a, const float* b, long n, const float* scale_dev, float factor,

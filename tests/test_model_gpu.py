@@ -460,3 +460,24 @@ def test_optimizer_step_with_closure_runs_backward():
 
     loss = opt.step(closure)
     assert loss is not None and torch.isfinite(loss) and not torch.equal(before, m.arena.params)
+
+
+@pytest.mark.gpu
+def test_iteration_buffer_advances_with_the_training_step_only():
+    """vit_som.py:104 `self.iteration += 1`: the device buffer moves inside the step's own loss kernel (no ATen
+    launch); validation leaves it alone; state_dict round-trips it."""
+    from oracle.gen_golden import make_config
+    torch.manual_seed(0)
+    cfg = make_config(3, 32, 4, 192, 2, 3, 96, 2, (4, 4), 10, 8, gamma=0.01, Tmax=4.0, Tmin=0.1)
+    model = build(cfg)
+    model.set_schedule(64, 10)
+    (opt,), _ = model.configure_optimizers()
+    x = torch.randn(8, 3, 32, 32, device=DEV)
+    y = torch.randint(0, 10, (8,), device=DEV)
+    for _ in range(3):
+        model.training_step((x, y), 0).backward()
+        opt.step()
+    model.validation_step((x, y), 0)
+    assert int(model.iteration) == 3 and model.state_dict()["iteration"].item() == 3
+    model.train_step_fused(x, y)
+    assert int(model.iteration) == 4

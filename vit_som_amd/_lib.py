@@ -83,7 +83,7 @@ SIGNATURES = {
     "vsom_scaled_mul": (C.c_int, [c_fp, c_fp, c_fp, C.c_long, c_fp, C.c_float, c_stream]),
     "vsom_som_weighted_loss": (C.c_int, [c_fp, c_fp, c_fp, c_fp, C.c_float, c_fp, c_fp, c_fp, c_fp, C.c_int, C.c_int, C.c_int,
                                          c_fp, C.c_size_t, c_stream]),
-    "vsom_lincomb2": (C.c_int, [c_fp, c_fp, C.c_float, c_fp, C.c_float, c_stream]),
+    "vsom_lincomb2": (C.c_int, [c_fp, c_fp, C.c_float, c_fp, C.c_float, C.c_void_p, c_stream]),
     "vsom_scale_by": (C.c_int, [c_fp, C.c_long, c_fp, c_stream]),
     "vsom_reduce_slabs": (C.c_int, [c_fp, C.c_long, C.c_int, c_fp, C.c_long, c_stream]),
 }

@@ -195,9 +195,13 @@ __global__ __launch_bounds__(256) void scaled_mul_kernel(float* __restrict__ out
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) out[i] = v * a[i] * (b ? b[i] : 1.0f);
 }
 
-// out[0] = ca * a[0] + cb * b[0]   (total loss from the two loss sums; one lane)
-__global__ void lincomb2_kernel(float* __restrict__ out, const float* __restrict__ a, float ca, const float* __restrict__ b, float cb) {
-    if (threadIdx.x == 0) out[0] = fmaf(cb, b[0], ca * a[0]);
+// out[0] = ca * a[0] + cb * b[0]   (total loss from the two loss sums; one lane) and, with it, the step counter
+__global__ void lincomb2_kernel(float* __restrict__ out, const float* __restrict__ a, float ca, const float* __restrict__ b, float cb,
+                                long long* __restrict__ counter) {
+    if (threadIdx.x == 0) {
+        out[0] = fmaf(cb, b[0], ca * a[0]);
+        if (counter) counter[0] += 1;
+    }
 }
 
 // batched 32x32-tile transpose through LDS; blockIdx.y = tensor, blockIdx.x = tile (surplus tiles exit)
@@ -264,9 +268,9 @@ int vsom_scaled_mul(float* out, const float* a, const float* b, long n, const fl
     VSOM_LAUNCH_CHECK("scaled_mul_kernel");
 }
 
-int vsom_lincomb2(float* out, const float* a, float ca, const float* b, float cb, vsom_stream_t stream) {
+int vsom_lincomb2(float* out, const float* a, float ca, const float* b, float cb, int64_t* counter, vsom_stream_t stream) {
     VSOM_REQUIRE(out && a && b, VSOM_EINVAL, "lincomb2: null pointer");
-    hipLaunchKernelGGL(lincomb2_kernel, dim3(1), dim3(64), 0, stream, out, a, ca, b, cb);
+    hipLaunchKernelGGL(lincomb2_kernel, dim3(1), dim3(64), 0, stream, out, a, ca, b, cb, reinterpret_cast<long long*>(counter));
     VSOM_LAUNCH_CHECK("lincomb2_kernel");
 }
 

@@ -1197,8 +1197,9 @@ class ViTSOM(_ArenaOwner, _Base):
             ops.l1_unpatchify(a.pred, x, a.main_sum, dpred=a.dpred if want_grad else None, grad_scale=1.0 / x.numel(),
                               p=self.vit.patch_embed.patch_size[0])
             main_scale = 1.0 / x.numel()
-        # total = main + gamma_t * som from the two device-side sums, in one tiny kernel (no ATen arithmetic in the step)
-        ops.lincomb2(a.total, a.main_sum, main_scale, s.loss_sum, gamma_t / (B * K))
+        # total = main + gamma_t * som from the two device-side sums, in one tiny kernel that also advances the
+        # `iteration` buffer of a training step (vit_som.py:104): no ATen kernel in the step
+        ops.lincomb2(a.total, a.main_sum, main_scale, s.loss_sum, gamma_t / (B * K), counter=self.iteration if want_grad else None)
         self._last = _LossParts(a.main_sum, main_scale, s.loss_sum, 1.0 / (B * K), a.total[0], gamma_t, T)
         return a.total[0]
 
@@ -1344,8 +1345,7 @@ class ViTSOM(_ArenaOwner, _Base):
         return total
 
     def _advance(self):
-        self._it += 1
-        self.iteration += 1                                             # vit_som.py:104 (device buffer, no sync)
+        self._it += 1                                                   # the device buffer moved with the loss (_forward_losses)
 
     def validation_step(self, batch, batch_idx):
         """vit_som.py:107-125 (full gamma, current temperature, no schedule update)."""

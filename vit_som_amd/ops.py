@@ -410,9 +410,12 @@ def som_weighted_loss(dist, weights, loss_sum, inv_nx=None, inv_nw=None, grad_sc
     return loss_sum
 
 
-def lincomb2(out, a, ca, b, cb):
-    """out[0] = ca * a[0] + cb * b[0] (device scalars)."""
-    check(lib.vsom_lincomb2(ptr(out), ptr(a), float(ca), ptr(b), float(cb), stream()), "vsom_lincomb2")
+def lincomb2(out, a, ca, b, cb, counter=None):
+    """out[0] = ca * a[0] + cb * b[0] (device scalars); `counter` (a 0-dim int64 device tensor) += 1 in the same launch."""
+    if counter is not None:
+        assert counter.dtype == torch.int64 and counter.is_cuda and counter.numel() == 1
+    check(lib.vsom_lincomb2(ptr(out), ptr(a), float(ca), ptr(b), float(cb), None if counter is None else counter.data_ptr(), stream()),
+          "vsom_lincomb2")
     return out
 
 
