@@ -256,6 +256,30 @@ def test_attention(ops, B, N, H, hd):
     assert rel_err(dqkv.cpu(), q64.grad) < 5e-6
 
 
+@pytest.mark.parametrize("B,N,H,hd", [(4, 65, 3, 64), (3, 64, 2, 64), (2, 50, 3, 64), (3, 33, 2, 64), (2, 17, 1, 64), (2, 65, 3, 32),
+                                       (2, 49, 2, 16), (2, 197, 2, 8)])
+def test_attention_backward_forms_give_the_same_bits(ops, B, N, H, hd):
+    """The short-sequence backward exists as two launches (hook 0), as one launch whose dK/dV phase re-uses the P and dS
+    blocks of the dQ phase (1, the default where the shape allows) and as one launch that recomputes them (2): same
+    arithmetic in the same order, so the gradients must be identical bit for bit -- incl. a ragged last tile (N = 50)
+    and shapes on which the default falls back to the other forms."""
+    E = H * hd
+    qkv, dout = dev(rnd(B, N, 3 * E, seed=11)), dev(rnd(B, N, E, seed=12))
+    out = torch.empty(B, N, E, device=DEV); lse = torch.empty(B, H, N, device=DEV)
+    ops.attention_fwd(qkv, out, lse, B, N, H, hd)
+    got = []
+    try:
+        for mode in (0, 1, 2):
+            ops.set_attention_fused(mode)
+            dqkv = torch.full((B, N, 3 * E), float("nan"), device=DEV); delta = torch.full((B, H, N), float("nan"), device=DEV)
+            ops.attention_bwd(qkv, out, dout, lse, dqkv, delta, B, N, H, hd)
+            got.append((dqkv, delta))
+    finally:
+        ops.set_attention_fused(1)
+    for dqkv, delta in got[1:]:
+        assert torch.equal(dqkv, got[0][0]) and torch.equal(delta, got[0][1])
+
+
 def test_attention_large_scores(ops):
     """online-softmax rescale path: a key in the SECOND 64-key chunk dominates."""
     B, N, H, hd = 1, 130, 1, 16

@@ -39,7 +39,8 @@
 
 namespace vsom {
 
-// test hook (vsom_set_attention_fused): 0 keeps the short-sequence backward as two launches
+// test / measurement hook (vsom_set_attention_fused): 0 keeps the short-sequence backward as two launches, 1 is the
+// default (one launch; scores shared between its phases where the shape allows), 2 one launch with recomputed scores
 static std::atomic<int> g_attn_fused{1};
 
 // tools/attn_lab.hip builds this file with VSOM_ATTN_STAMPS: thread 0 of every workgroup records the 100 MHz
@@ -958,6 +959,178 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(const float* __rest
     ATTN_STAMP(3);
 }
 
+// ------------------------------------------------------------------ backward, fused, scores shared
+// attn_bwd_fused_kernel computes the scores and dP twice: transposed per query tile for dQ, and again per key
+// tile for dK / dV (7 N x N x hd products for the 5 the mathematics has), and at two workgroups per CU its
+// compute phases keep the f32 matrix pipe ~72 % busy.  With ONE 16-token tile per wave (4 tiles, N <= 65) the wave
+// keeps the P^T and dS^T blocks it formed for dQ in registers (32 of them); after the dQ phase the K and V regions
+// are dead -- every wave first takes what the second phase still needs from them (its own k / v rows for the
+// token-0 terms, rows 0 aside) -- and hold P and dS as [query][key] matrices, which the key waves read back
+// transposed (conflict-free both ways at a row stride of 16 tiles + 4).  The dK / dV phase is then the two
+// accumulations only: 320 MFMAs per wave instead of 448, and no second exp pass.  Needs 2 x (16 tiles)(16 tiles + 4)
+// floats <= the K + V regions: hd = 64.  The values are the same bits as the recomputed ones (a product commutes and
+// the reduction order over the head dim is the same), so the result is bit-identical to the other forms.
+template <int HDP, bool EXTRA>
+__global__ __launch_bounds__(256) void attn_bwd_shared_kernel(const float* __restrict__ qkv, const float* __restrict__ out,
+                                                              const float* __restrict__ dout, const float* __restrict__ lse,
+                                                              float* __restrict__ dqkv, float* __restrict__ delta, int N,
+                                                              int H, int hd, float scale) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int NDT = ACfg<HDP>::NDT;
+    constexpr int NMM = ACfg<HDP>::NMM;
+    constexpr int S = ACfg<HDP>::S;
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const int E = H * hd, E3 = 3 * E;
+    const int ntile = EXTRA ? (N - 1) >> 4 : (N + 15) >> 4;           // == number of waves, <= 4
+    const int nrows = EXTRA ? N : ntile << 4;
+    const int nrp = (nrows + 3) & ~3;
+    const int PS = 16 * ntile + 4;                                     // row stride of the P / dS matrices
+    float* Ks = smem;
+    float* Vs = Ks + nrows * S;
+    float* Qs = Vs + nrows * S;
+    float* Ds = Qs + nrows * S;
+    float* Ls = Ds + nrows * S;
+    float* Es = Ls + nrp;
+    float* PA = Es + nrp;                                              // [nwaves][3 HDP]: gq | gk | gv of token 0
+    float* X2 = PA + (blockDim.x >> 6) * 3 * HDP;                      // k, v of token 0 once the K / V regions are reused
+    float* X3 = X2 + HDP;
+    float* Pm = Ks;                                                    // [16 ntile][PS] after the dQ phase
+    float* Dm = Vs;
+    const float* base = qkv + (long)b * N * E3 + h * hd;
+    const long obase = (long)b * N * E + h * hd;
+    const long srow0 = ((long)b * H + h) * N;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    const int r = lane & 15, qp = lane >> 4;
+    float qf[NMM], dof[NMM], of[NMM];
+    ATTN_STAMP(0);
+    ATTN_STAMP_HWID();
+    const int own = tok<EXTRA>(wave, r);                               // the wave's query row in phase 1, key row in phase 2
+    const bool ook = own < N;
+    load_frag<HDP>(qf, base + (long)own * E3, qp, ook, hd);
+    load_frag<HDP>(dof, dout + obase + (long)own * E, qp, ook, hd);
+    load_frag<HDP>(of, out + obase + (long)own * E, qp, ook, hd);
+    float o0 = 0.f;
+    if (EXTRA && lane < hd) o0 = out[obase + lane];
+    float l_r = 0.f;
+    if ((int)threadIdx.x < N) l_r = lse[srow0 + threadIdx.x];
+    stage_rows_quad<HDP>(Ks, base + E, E3, Vs, base + 2 * E, E3, Qs, base, E3, Ds, dout + obase, E, N, nrows);
+    for (int i = threadIdx.x; i < nrp; i += blockDim.x) {
+        Ls[i] = (i == (int)threadIdx.x) ? l_r : ((i < N) ? lse[srow0 + i] : 0.f);
+        Es[i] = 0.f;
+    }
+    __syncthreads();
+    ATTN_STAMP(1);
+
+    // ---- phase 1: dQ and D; P^T and dS^T of the wave's query tile stay in registers
+    float D0 = 0.f, l0 = 0.f, gq0 = 0.f;
+    if (EXTRA) {
+        D0 = wave_sum64((HDP >= 64 || lane < HDP) ? Ds[lane] * o0 : 0.f);
+        l0 = Ls[0];
+        if (wave == 0 && lane == 0) { delta[srow0] = D0; Es[0] = D0; }
+    }
+    f32x4 pT[4], dsT[4];
+    {
+        const int query = own;
+        const bool qok = ook;
+        float D = 0.f;
+#pragma unroll
+        for (int mm = 0; mm < NMM; ++mm) D = fmaf(dof[mm], of[mm], D);
+        D = group_sum(D);
+        if (qp == 0 && qok) { delta[srow0 + query] = D; Es[query] = D; }
+        const float lq = qok ? Ls[query] : 0.f;
+        f32x4 dq[NDT];
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (EXTRA) {                                                   // token 0 as a key
+            const float s0 = frag_dot_row<HDP>(qf, Ks, qp) * scale;
+            const float dp0 = frag_dot_row<HDP>(dof, Vs, qp);
+            const float p0 = __expf(s0 - lq);
+            axpy_row<HDP>(dq, p0 * (dp0 - D) * scale, Ks, qp);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            if (t < ntile) {
+                f32x4 sc, dp;
+                score_tile2<HDP>(Ks, tok<EXTRA>(t, 0), qf, Vs, tok<EXTRA>(t, 0), dof, r, qp, sc, dp);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int key = tok<EXTRA>(t, 4 * qp + e);
+                    const float p = (EXTRA || (key < N && qok)) ? __expf(sc[e] * scale - lq) : 0.f;
+                    pT[t][e] = p;
+                    dsT[t][e] = p * (dp[e] - D) * scale;
+                }
+                accum_tile<HDP>(dq, Ks, tok<EXTRA>(t, 0), r, qp, dsT[t]);
+            }
+        }
+        store_rows<HDP>(dq, dqkv + ((long)b * N + query) * E3 + h * hd, qp, qok, hd);
+        if (EXTRA) gq0 += tok0_dq_partial<HDP>(Qs, Ds, Ks, Vs, tok<EXTRA>(wave, 0), l0, D0, scale, lane, r, qp);
+    }
+    if (EXTRA && (HDP >= 64 || lane < HDP)) PA[wave * 3 * HDP + lane] = gq0;
+    __syncthreads();                                                   // Es (D of every row) and the dQ partials complete
+    ATTN_STAMP(2);
+
+    // ---- between the phases: what phase 2 still needs from K and V, then P and dS take their place
+    float gk0 = 0.f, gv0 = 0.f, p0k = 0.f, w0k = 0.f;
+    if (EXTRA) {
+        if (wave == 0)
+            tok0_dq_combine<HDP>(Qs, Ds, Ks, Vs, PA, 3 * HDP, nwaves, l0, D0, scale, dqkv + (long)b * N * E3 + h * hd, hd, lane);
+        float kf[NMM], vf[NMM];                                        // token 0 as a query against the wave's own keys
+        load_frag_lds<HDP>(kf, Ks, own, qp);
+        load_frag_lds<HDP>(vf, Vs, own, qp);
+        const float s0 = frag_dot_row<HDP>(kf, Qs, qp) * scale;
+        const float dp0 = frag_dot_row<HDP>(vf, Ds, qp);
+        p0k = __expf(s0 - Ls[0]);
+        w0k = p0k * (dp0 - Es[0]) * scale;
+        if (wave == nwaves - 1 && (HDP >= 64 || lane < HDP)) { X2[lane] = Ks[lane]; X3[lane] = Vs[lane]; }
+    }
+    __syncthreads();                                                   // K and V are dead
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+        if (t < ntile) {
+            *reinterpret_cast<f32x4*>(Pm + (16 * wave + r) * PS + 16 * t + 4 * qp) = pT[t];
+            *reinterpret_cast<f32x4*>(Dm + (16 * wave + r) * PS + 16 * t + 4 * qp) = dsT[t];
+        }
+    __syncthreads();
+
+    // ---- phase 2: dK, dV from the stored P and dS (rows: queries of tile t, column: the wave's own key)
+    {
+        const int key = own;
+        const bool kok = ook;
+        f32x4 dk[NDT], dv[NDT];
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) { dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        if (EXTRA) {                                                   // token 0 as a query
+            axpy_row<HDP>(dv, p0k, Ds, qp);
+            axpy_row<HDP>(dk, w0k, Qs, qp);
+        }
+        for (int t = 0; t < ntile; ++t) {
+            f32x4 p, ds;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                p[e] = Pm[(16 * t + 4 * qp + e) * PS + 16 * wave + r];
+                ds[e] = Dm[(16 * t + 4 * qp + e) * PS + 16 * wave + r];
+            }
+            accum_tile2<HDP>(dv, Ds, p, dk, Qs, ds, tok<EXTRA>(t, 0), r, qp);
+        }
+        float* drow = dqkv + ((long)b * N + key) * E3 + h * hd;
+        store_rows<HDP>(dk, drow + E, qp, kok, hd);
+        store_rows<HDP>(dv, drow + 2 * E, qp, kok, hd);
+        if (EXTRA) tok0_dkv_partial<HDP>(X2, X3, Qs, Ds, Ls, Es, tok<EXTRA>(wave, 0), scale, lane, r, qp, gk0, gv0);
+    }
+    if (EXTRA) {
+        if (HDP >= 64 || lane < HDP) {
+            PA[wave * 3 * HDP + HDP + lane] = gk0;
+            PA[wave * 3 * HDP + 2 * HDP + lane] = gv0;
+        }
+        __syncthreads();
+        if (wave == 0) {
+            float* drow = dqkv + (long)b * N * E3 + h * hd;
+            tok0_dkv_combine<HDP>(Qs, Ds, X2, X3, PA + HDP, 3 * HDP, nwaves, Ls[0], Es[0], scale, drow + E, drow + 2 * E, hd, lane);
+        }
+    }
+    ATTN_STAMP(3);
+}
+
 // ------------------------------------------------------------------ host side
 // (A persistent variant -- workgroups looping over (image, head) items with register prefetch of
 // the next item's rows -- was measured and rejected: the extra registers drop residency and N = 65 got
@@ -1002,7 +1175,17 @@ static int launch_bwd_t(const float* qkv, const float* out, const float* dout, c
     const dim3 block(64 * attn_waves(N));
     // all four slices in LDS and still two workgroups per CU -> one fused launch (vector path only)
     const size_t fused_lds = attn_fused_lds_bytes(N, HDP);
-    if (ACfg<HDP>::VEC && fused_lds <= 80 * 1024 && g_attn_fused.load(std::memory_order_relaxed)) {
+    const int mode = g_attn_fused.load(std::memory_order_relaxed);     // 0: two launches, 1: default, 2: fused with recomputed scores
+    if constexpr (ACfg<HDP>::VEC) {
+        const int nt = attn_tiles(N), nrows = use_extra(N) ? N : nt * 16;
+        const size_t shared_lds = fused_lds + 2 * HDP * sizeof(float);
+        if (mode == 1 && nt <= 4 && attn_waves(N) == nt && 16 * nt * (16 * nt + 4) <= nrows * (HDP + 4) && shared_lds <= 80 * 1024) {
+            hipLaunchKernelGGL((attn_bwd_shared_kernel<HDP, EXTRA>), dim3(B * H), block, shared_lds, st, qkv, out, dout, lse, dqkv,
+                               delta, N, H, hd, scale);
+            VSOM_LAUNCH_CHECK("attn_bwd_shared_kernel");
+        }
+    }
+    if (ACfg<HDP>::VEC && fused_lds <= 80 * 1024 && mode) {
         hipLaunchKernelGGL((attn_bwd_fused_kernel<HDP, EXTRA>), dim3(B * H), block, fused_lds, st, qkv, out, dout, lse, dqkv,
                            delta, N, H, hd, scale);
         VSOM_LAUNCH_CHECK("attn_bwd_fused_kernel");
@@ -1043,7 +1226,7 @@ using namespace vsom;
 extern "C" {
 
 int vsom_set_attention_fused(int fused) {
-    g_attn_fused.store(fused ? 1 : 0, std::memory_order_relaxed);
+    g_attn_fused.store(fused < 0 ? 0 : (fused > 2 ? 2 : fused), std::memory_order_relaxed);
     return VSOM_OK;
 }
 

@@ -383,9 +383,10 @@ def fill(t, value):
     return t
 
 
-def set_attention_fused(fused: bool):
-    """Test hook: False runs the short-sequence attention backward as two launches."""
-    check(lib.vsom_set_attention_fused(int(bool(fused))), "vsom_set_attention_fused")
+def set_attention_fused(fused):
+    """Test / measurement hook: False (0) runs the short-sequence attention backward as two launches, True (1) is the
+    default (one launch, scores shared between its phases where the shape allows), 2 = one launch with recomputed scores."""
+    check(lib.vsom_set_attention_fused(int(fused)), "vsom_set_attention_fused")
 
 
 def scaled_mul(out, a, b=None, scale_dev=None, factor=1.0):
