@@ -1,0 +1,622 @@
+// CANDIDATE, not part of the library: vit_som_amd/csrc/bmu_x3.hip plus bmu_x3_ws_kernel, the BMU contraction with
+// the waves of a workgroup specialised (4 consumer waves of 128 x 96 outputs that only read fragments and issue MFMAs,
+// 4 loader waves that only load, split and fill a two-slot LDS ring; also tried: 8 consumers of 64 x 96 + 4 loaders).
+// Identical results to bmu_x3_kernel on every shape tried, and SLOWER: 82-86 us against 77 at the c3 shape.  Ablations:
+// loaders alone 52-55 us, consumers alone (no global loads) 53-55 us, and the two do not overlap.  The ISA shows why
+// the loaders do not get ahead: the compiler's own waits in front of the split run down to vmcnt(0) before the next
+// stage's loads are issued (the loop has branches, so it counts conservatively) -- ONE stage in flight whatever the
+// number of register sets, i.e. 57 KB per ~3 us of memory latency per CU, the same ~19 GB/s per CU the lock-step
+// kernel reaches.  Loads it cannot see (asm) would fix the count, but registers that hold in-flight data get copied
+// by the compiler before a hand-placed wait (profiles/r02_attention_lab_findings.txt) -- the way out is LDS-DMA,
+// which needs the fp32 tiles in LDS first (no room next to the plane ring).  tools/mfma_bf16_probe.hip: the matrix
+// pipe itself sustains 32 cycles per v_mfma_f32_32x32x16_bf16 (2.1 PF) for any mix of dependent chains.
+// BMU distance pass for the cosine SOM (models/som_layer.py:119-122, 83-89):
+//     dist[i,k] = 1 - <x_i, w_k> / (max(|x_i|, eps) max(|w_k|, eps)),   bmu[i] = first argmin_k dist[i,k]
+// as a reduced-precision contraction + exact re-rank (the only way off the f32-MFMA roofline).
+//
+//  1. bmu_x3_kernel: X W^T on the bf16 matrix cores from a TWO-piece round-to-nearest split of each fp32
+//     operand, a = a1 + a2 + r2 with |a2| <= 2^-9 |a|, |r2| <= 2^-17 |a|, three products a2 b1 + a1 b2 + a1 b1
+//     (fp32 accumulate).  Dropped: a1 s2 + r2 b1 + r1 s1, each <= 2^-16 |a||b| (r1 = a - a1, s* likewise), so
+//     |error of the normalised dot| <= 3 * 2^-16 = 4.6e-5 in the worst case (Cauchy-Schwarz; observed ~1e-7:
+//     the terms carry random signs) -- half the matrix-core work of the six-product engine of gemm_x6.h and a
+//     sixteenth of the f32 MFMA's.  The squared row norms of X and W ride along (the tiles pass through the
+//     registers anyway), so the two row-norm passes over X and W disappear.  Reduction over L split across
+//     workgroups, partial dots / norms in fp32 slabs summed in fixed order (bitwise reproducible).
+//  2. bmu_norms_kernel: inv_nx, inv_nw from the norm partials.
+//  3. bmu_x3_finalize_kernel (one workgroup per sample): distances, approximate minimum, then every prototype
+//     within BMU_WINDOW of it is RE-RANKED with an exact dot product (fp32 products accumulated in fp64 over the
+//     whole row); the exact distances replace the approximate ones in dist and the BMU is their first minimum.
+//     Since BMU_WINDOW > 2 x the contraction's error bound, the true minimum is always among the candidates and
+//     every prototype outside keeps a value above the winner's: bmu == argmin(dist) holds exactly, and bmu is
+//     the argmin of distances that are exact to fp64 rounding wherever it matters.
+#include "gemm_x6.h"
+
+#include <atomic>
+
+namespace vsom {
+
+static std::atomic<int> g_bmu_ws{1};       // measurement hook (vsom_set_bmu_wave_specialised): 0 = the lock-step kernel
+
+constexpr float BMU_WINDOW = 1.0e-4f;      // > 2 * 3 * 2^-16 (split error, worst case) + fp32 accumulation slack
+
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+
+struct BmuP {
+    const float* X; long ldx; const float* W;
+    int B, K, L;
+    int ktiles_per_split;
+    float* slab; long slab_stride;      // [splits][B*K]
+    float* xsq; float* wsq;             // [splits][B], [splits][K] partial squared norms
+    unsigned x_bytes, w_bytes;
+};
+
+// 4 floats -> two planes of 4 bf16 (round to nearest even; v_cvt_pk_bf16_f32)
+__device__ __forceinline__ void x3_split(f32x4 v, uint2& p1, uint2& p2) {
+    const bf16x2_t a01 = {(__bf16)v[0], (__bf16)v[1]}, a23 = {(__bf16)v[2], (__bf16)v[3]};
+    const unsigned u01 = __builtin_bit_cast(unsigned, a01), u23 = __builtin_bit_cast(unsigned, a23);
+    const float r0 = v[0] - x6_float(u01 << 16), r1 = v[1] - x6_float(u01 & 0xffff0000u);
+    const float r2 = v[2] - x6_float(u23 << 16), r3 = v[3] - x6_float(u23 & 0xffff0000u);
+    const bf16x2_t b01 = {(__bf16)r0, (__bf16)r1}, b23 = {(__bf16)r2, (__bf16)r3};
+    p1.x = u01; p1.y = u23;
+    p2.x = __builtin_bit_cast(unsigned, b01); p2.y = __builtin_bit_cast(unsigned, b23);
+}
+
+// k-contiguous fp32 tile ROWS x 32 staged by NT threads: thread t loads float4 (row = p * (NT / 8) + t / 8, k = (t % 8) * 4)
+template <int ROWS, int NT> struct X3Stage { f32x4 v[ROWS / (NT / 8)]; };
+template <int ROWS, int NT> struct X3Off { unsigned off[ROWS / (NT / 8)]; };
+template <int ROWS, int NT>
+__device__ __forceinline__ void x3_init(X3Off<ROWS, NT>& o, long ld, int row0, int nrows, int t) {
+#pragma unroll
+    for (int p = 0; p < ROWS / (NT / 8); ++p) {
+        const int row = row0 + p * (NT / 8) + (t >> 3);
+        o.off[p] = (row < nrows) ? (unsigned)(((long)row * ld + ((t & 7) << 2)) << 2) : OOB;
+    }
+}
+template <int ROWS, int NT>
+__device__ __forceinline__ void x3_load(X3Stage<ROWS, NT>& s, __amdgpu_buffer_rsrc_t rsrc, const X3Off<ROWS, NT>& o, int k0, int K, int t) {
+    const bool kok = k0 + ((t & 7) << 2) < K;
+    const unsigned kbytes = (unsigned)k0 << 2;
+#pragma unroll
+    for (int p = 0; p < ROWS / (NT / 8); ++p) s.v[p] = bload4(rsrc, (kok && o.off[p] != OOB) ? o.off[p] + kbytes : OOB);
+}
+
+// tile (WAVES_M WM 32) x (WAVES_N WN 32) x 32; LDS: 2 planes x (BM + BN) rows x 64 B (swizzled image of gemm_x6.h).  The split costs ~18 VALU per
+// float4 against 3 (not 6) MFMAs per 16-deep step, so the tile has to be LARGE to keep the loop off the VALU issue
+// limit: 7.5 VALU per MFMA at 128 x 128 (measured 89 us, issue-bound), 3.5 at 256 x 192.
+template <int WM, int WN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void bmu_x3_kernel(const BmuP g) {
+    constexpr int BM = WAVES_M * WM * 32, BN = WAVES_N * WN * 32, NT = WAVES_M * WAVES_N * 64, RPP = NT / 8;
+    constexpr int PA = BM * X6_RS, PB = BN * X6_RS;
+    __shared__ __attribute__((aligned(16))) char lds[2 * (PA + PB)];
+    char* As = lds; char* Bs = lds + 2 * PA;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int wm0 = (wave / WAVES_N) * (WM * 32), wn0 = (wave % WAVES_N) * (WN * 32);
+    const int tiles_n = (g.K + BN - 1) / BN, tiles_m = (g.B + BM - 1) / BM, ntiles = tiles_m * tiles_n;
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);          // split-major: an XCD owns a slice of L
+    const int z = lid / ntiles, rem = lid - z * ntiles;
+    const int tm = rem % tiles_m, tn = rem / tiles_m;          // neighbours share the (larger) W panel
+    const int bm0 = tm * BM, bn0 = tn * BN;
+    const int ktiles = (g.L + 31) >> 5;
+    const int kt_begin = z * g.ktiles_per_split;
+    int kt_end = kt_begin + g.ktiles_per_split;
+    if (kt_end > ktiles) kt_end = ktiles;
+
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.X), 0, (int)g.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.W), 0, (int)g.w_bytes, 0x00020000);
+    // (a second staging register set -- two k-tiles of loads in flight -- measured slower: 95 vs 87 us at 128 x 128)
+    X3Stage<BM, NT> sa0; X3Stage<BN, NT> sb0;
+    X3Off<BM, NT> oa; X3Off<BN, NT> ob;
+    x3_init<BM, NT>(oa, g.ldx, bm0, g.B, t);
+    x3_init<BN, NT>(ob, g.L, bn0, g.K, t);
+    const bool want_x = tn == 0, want_w = tm == 0;            // squared-norm partials: one column / row of tiles
+    float ssa[BM / RPP], ssb[BN / RPP];
+#pragma unroll
+    for (int p = 0; p < BM / RPP; ++p) ssa[p] = 0.f;
+#pragma unroll
+    for (int p = 0; p < BN / RPP; ++p) ssb[p] = 0.f;
+
+    auto gload = [&](X3Stage<BM, NT>& sa, X3Stage<BN, NT>& sb, int kt) {       // kt beyond the range: k >= L -> zeros (never stored)
+        x3_load<BM, NT>(sa, rsA, oa, kt << 5, g.L, t);
+        x3_load<BN, NT>(sb, rsB, ob, kt << 5, g.L, t);
+    };
+    auto lstore = [&](const X3Stage<BM, NT>& sa, const X3Stage<BN, NT>& sb) {
+#pragma unroll
+        for (int p = 0; p < BM / RPP; ++p) {
+            const f32x4 v = sa.v[p];
+            if (want_x) ssa[p] += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+            uint2 p1, p2;
+            x3_split(v, p1, p2);
+            char* dst = As + x6_piece_off(p * RPP + (t >> 3), t & 7);
+            *reinterpret_cast<uint2*>(dst) = p1;
+            *reinterpret_cast<uint2*>(dst + PA) = p2;
+        }
+#pragma unroll
+        for (int p = 0; p < BN / RPP; ++p) {
+            const f32x4 v = sb.v[p];
+            if (want_w) ssb[p] += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+            uint2 p1, p2;
+            x3_split(v, p1, p2);
+            char* dst = Bs + x6_piece_off(p * RPP + (t >> 3), t & 7);
+            *reinterpret_cast<uint2*>(dst) = p1;
+            *reinterpret_cast<uint2*>(dst + PB) = p2;
+        }
+    };
+    auto mfma_tile = [&]() {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 a[WM][2], b[WN][2];
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl)
+                    a[i][pl] = *reinterpret_cast<const bf16x8*>(As + pl * PA + x6_chunk_off(wm0 + i * 32 + r, 2 * ks + h));
+#pragma unroll
+            for (int j = 0; j < WN; ++j)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl)
+                    b[j][pl] = *reinterpret_cast<const bf16x8*>(Bs + pl * PB + x6_chunk_off(wn0 + j * 32 + r, 2 * ks + h));
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j) {
+                    f32x16 c = acc[i][j];
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], c, 0, 0, 0);   // 2^-9 terms
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], c, 0, 0, 0);   // leading term
+                    acc[i][j] = c;
+                }
+        }
+    };
+    if (kt_begin < kt_end) {
+        gload(sa0, sb0, kt_begin);
+        lstore(sa0, sb0);
+    }
+    __syncthreads();
+    for (int kt = kt_begin; kt + 1 < kt_end; ++kt) {       // branch-free body, last k-tile peeled (gemm_x6.h)
+        gload(sa0, sb0, kt + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_tile();
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        lstore(sa0, sb0);
+        __syncthreads();
+    }
+    if (kt_begin < kt_end) mfma_tile();
+
+    // squared-norm partials: the 8 threads of a row are 8 consecutive lanes
+    if (want_x) {
+#pragma unroll
+        for (int p = 0; p < BM / RPP; ++p) {
+            float v = ssa[p];
+            v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
+            const int m = bm0 + p * RPP + (t >> 3);
+            if ((t & 7) == 0 && m < g.B) g.xsq[(long)z * g.B + m] = v;
+        }
+    }
+    if (want_w) {
+#pragma unroll
+        for (int p = 0; p < BN / RPP; ++p) {
+            float v = ssb[p];
+            v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
+            const int n = bn0 + p * RPP + (t >> 3);
+            if ((t & 7) == 0 && n < g.K) g.wsq[(long)z * g.K + n] = v;
+        }
+    }
+    // slab[z][m * K + n]; accumulator register v: row (v & 3) + 8 (v >> 2) + 4 h, column r
+    float* sl = g.slab + (long)z * g.slab_stride;
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+            const int n = bn0 + wn0 + j * 32 + r;
+            if (n >= g.K) continue;
+            const int mb = bm0 + wm0 + i * 32 + 4 * h;
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int m = mb + (v & 3) + 8 * (v >> 2);
+                if (m < g.B) sl[(long)m * g.K + n] = acc[i][j][v];
+            }
+        }
+}
+
+// ---- the same contraction with the waves of a workgroup SPECIALISED (round 2).  In bmu_x3_kernel all eight waves
+// walk through "wait for the loads, split, store to LDS, barrier, fragment reads + MFMAs, barrier" together, one
+// workgroup per CU: nothing overlaps the split (VALU) and the memory latency with the matrix cores -- a k-tile costs
+// ~6200 cycles for 1152 cycles of MFMA issue per wave.  Here NL loader waves do nothing but load the fp32 tiles (two
+// stages of global loads in flight, counted waits), split them and fill a two-slot LDS ring; the NC consumer waves
+// do nothing but read fragments and issue MFMAs.  One barrier per stage: stage k is stored between barriers k-1 and
+// k into slot k & 1 while the consumers work on slot (k-1) & 1.  Same arithmetic per output element in the same
+// order as bmu_x3_kernel (the split, the three products per 16-deep step, the k order): identical slabs.
+template <int WM, int WN, int WAVES_M, int WAVES_N, int NL, int ABL = 0>
+__global__ __launch_bounds__((WAVES_M * WAVES_N + NL) * 64) void bmu_x3_ws_kernel(const BmuP g) {
+    constexpr int BM = WAVES_M * WM * 32, BN = WAVES_N * WN * 32, NC = WAVES_M * WAVES_N, LT = NL * 64;
+    constexpr int PA = BM * X6_RS, PB = BN * X6_RS, SLOT = 2 * (PA + PB);
+    constexpr int FA = BM * 8 / LT, FB = BN * 8 / LT;
+    static_assert((BM * 8) % LT == 0 && (BN * 8) % LT == 0, "loader float4 count");
+    __shared__ __attribute__((aligned(16))) char lds[2 * SLOT];
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int tiles_n = (g.K + BN - 1) / BN, tiles_m = (g.B + BM - 1) / BM, ntiles = tiles_m * tiles_n;
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);          // split-major: an XCD owns a slice of L
+    const int z = lid / ntiles, rem = lid - z * ntiles;
+    const int tm = rem % tiles_m, tn = rem / tiles_m;          // neighbours share the (larger) W panel
+    const int bm0 = tm * BM, bn0 = tn * BN;
+    const int ktiles = (g.L + 31) >> 5;
+    const int kt_begin = z * g.ktiles_per_split;
+    int kt_end = kt_begin + g.ktiles_per_split;
+    if (kt_end > ktiles) kt_end = ktiles;
+    const int total = kt_end - kt_begin;                       // >= 1 by construction of the split count
+    if (total <= 0) return;
+
+    if (wave >= NC) {
+        // ------------------------------------------------------------------ loaders
+        const int lt = t - NC * 64;
+        const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.X), 0, (int)g.x_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.W), 0, (int)g.w_bytes, 0x00020000);
+        // float4 number f = i * LT + lt of a [rows][8] tile: row = f >> 3, kq = f & 7 (k = 4 kq); kq = lt & 7 for every i
+        const int kq = lt & 7, r0 = lt >> 3;                   // row of float4 i: i * (LT / 8) + r0
+        constexpr int RSTEP = LT / 8;                          // a multiple of 4: the swizzle term of the image is the same for every i
+        static_assert(RSTEP % 4 == 0, "plane image swizzle period");
+        const unsigned oa0 = (unsigned)((((long)(bm0 + r0)) * g.ldx + 4 * kq) * 4), oas = (unsigned)((long)RSTEP * g.ldx * 4);
+        const unsigned ob0 = (unsigned)((((long)(bn0 + r0)) * g.L + 4 * kq) * 4), obs = (unsigned)((long)RSTEP * g.L * 4);
+        const int la0 = x6_piece_off(r0, kq), lb0 = 2 * PA + la0;   // + i * RSTEP * X6_RS
+        const bool want_x = tn == 0, want_w = tm == 0;        // squared-norm partials: one column / row of tiles
+        float ssa[FA], ssb[FB];
+#pragma unroll
+        for (int i = 0; i < FA; ++i) ssa[i] = 0.f;
+#pragma unroll
+        for (int i = 0; i < FB; ++i) ssb[i] = 0.f;
+        struct RS { f32x4 a[FA], b[FB]; };
+        RS R0, R1, R2;                                         // three stages of global loads in flight (the memory latency is ~3 us;
+                                                               // four sets of 14 float4 do not fit the register file next to the norms)
+        // UNCONDITIONAL loads (behind a branch the compiler cannot count them and waits vmcnt(0) before every use: the
+        // prefetch depth collapses to one stage): a stage past the end re-loads the last one, a k past L reads zeros
+        auto gload = [&](RS& R, int s) {
+            if (ABL == 2) return;                              // lab: no global loads (consumer-bound time)
+            s = s < total ? s : total - 1;
+            const int k0 = (kt_begin + s) << 5;
+            const unsigned kb = (k0 + 4 * kq < g.L) ? (unsigned)k0 << 2 : OOB;
+#pragma unroll
+            for (int i = 0; i < FA; ++i) R.a[i] = bload4(rsA, (bm0 + r0 + i * RSTEP < g.B && kb != OOB) ? oa0 + i * oas + kb : OOB);
+#pragma unroll
+            for (int i = 0; i < FB; ++i) R.b[i] = bload4(rsB, (bn0 + r0 + i * RSTEP < g.K && kb != OOB) ? ob0 + i * obs + kb : OOB);
+        };
+        auto lstore = [&](const RS& R, int s) {
+            char* slot = lds + (s & 1) * SLOT;
+#pragma unroll
+            for (int i = 0; i < FA; ++i) {
+                const f32x4 v = R.a[i];
+                if (want_x) ssa[i] += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+                uint2 p1, p2;
+                x3_split(v, p1, p2);
+                *reinterpret_cast<uint2*>(slot + la0 + i * RSTEP * X6_RS) = p1;
+                *reinterpret_cast<uint2*>(slot + PA + la0 + i * RSTEP * X6_RS) = p2;
+            }
+#pragma unroll
+            for (int i = 0; i < FB; ++i) {
+                const f32x4 v = R.b[i];
+                if (want_w) ssb[i] += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+                uint2 p1, p2;
+                x3_split(v, p1, p2);
+                *reinterpret_cast<uint2*>(slot + lb0 + i * RSTEP * X6_RS) = p1;
+                *reinterpret_cast<uint2*>(slot + PB + lb0 + i * RSTEP * X6_RS) = p2;
+            }
+        };
+        gload(R0, 0); gload(R1, 1); gload(R2, 2);
+        lstore(R0, 0);
+        gload(R0, 3);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                          // barrier 0: stage 0 is readable
+#define BMU_WS_STEP(RSET, k)                                             \
+        if ((k) >= total) break;                                         \
+        lstore(RSET, (k));                                               \
+        gload(RSET, (k) + 3);                                            \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               \
+        __builtin_amdgcn_s_barrier();
+        for (int s0 = 0; ; s0 += 3) {
+            BMU_WS_STEP(R1, s0 + 1)
+            BMU_WS_STEP(R2, s0 + 2)
+            BMU_WS_STEP(R0, s0 + 3)
+        }
+#undef BMU_WS_STEP
+        // squared-norm partials: the 8 threads of a row are 8 consecutive lanes
+        if (want_x) {
+#pragma unroll
+            for (int i = 0; i < FA; ++i) {
+                float v = ssa[i];
+                v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
+                const int m = bm0 + ((i * LT + lt) >> 3);
+                if (kq == 0 && m < g.B) g.xsq[(long)z * g.B + m] = v;
+            }
+        }
+        if (want_w) {
+#pragma unroll
+            for (int i = 0; i < FB; ++i) {
+                float v = ssb[i];
+                v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
+                const int n = bn0 + ((i * LT + lt) >> 3);
+                if (kq == 0 && n < g.K) g.wsq[(long)z * g.K + n] = v;
+            }
+        }
+        return;
+    }
+    // ---------------------------------------------------------------------- consumers
+    const int r = lane & 31, h = lane >> 5;
+    const int wm0 = (wave / WAVES_N) * (WM * 32), wn0 = (wave % WAVES_N) * (WN * 32);
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[i][j][v] = 0.f;
+    for (int s = 0; s < total; ++s) {
+        __builtin_amdgcn_s_barrier();                          // barrier s: stage s is readable
+        const char* As = lds + (s & 1) * SLOT;
+        const char* Bs = As + 2 * PA;
+        if (ABL == 1) continue;                                // lab: no fragment reads / MFMAs (loader-bound time)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 a[WM][2];
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl)
+                    a[i][pl] = *reinterpret_cast<const bf16x8*>(As + pl * PA + x6_chunk_off(wm0 + i * 32 + r, 2 * ks + h));
+#pragma unroll
+            for (int j = 0; j < WN; ++j) {                     // B fragments one column block at a time: registers
+                bf16x8 b[2];
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl)
+                    b[pl] = *reinterpret_cast<const bf16x8*>(Bs + pl * PB + x6_chunk_off(wn0 + j * 32 + r, 2 * ks + h));
+#pragma unroll
+                for (int i = 0; i < WM; ++i) {
+                    f32x16 c = acc[i][j];
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[0], c, 0, 0, 0);   // 2^-9 terms
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[1], c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[0], c, 0, 0, 0);   // leading term
+                    acc[i][j] = c;
+                }
+            }
+        }
+    }
+    // slab[z][m * K + n]; accumulator register v: row (v & 3) + 8 (v >> 2) + 4 h, column r
+    float* sl = g.slab + (long)z * g.slab_stride;
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+            const int n = bn0 + wn0 + j * 32 + r;
+            if (n >= g.K) continue;
+            const int mb = bm0 + wm0 + i * 32 + 4 * h;
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int m = mb + (v & 3) + 8 * (v >> 2);
+                if (m < g.B) sl[(long)m * g.K + n] = acc[i][j][v];
+            }
+        }
+}
+
+// inv[i] = 1 / max(sqrt(sum_z part[z][i]), eps)   (F.normalize's eps = 1e-12, som_layer.py:120-121)
+__global__ __launch_bounds__(256) void bmu_norms_kernel(const float* __restrict__ xsq, const float* __restrict__ wsq, int nz,
+                                                        int B, int K, float* __restrict__ inv_nx, float* __restrict__ inv_nw) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B + K) return;
+    const bool isx = i < B;
+    const float* p = isx ? xsq + i : wsq + (i - B);
+    const int n = isx ? B : K;
+    float s = 0.f;
+    for (int z = 0; z < nz; ++z) s += p[(long)z * n];
+    const float inv = 1.0f / fmaxf(sqrtf(s), 1e-12f);
+    if (isx) inv_nx[i] = inv; else inv_nw[i - B] = inv;
+}
+
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// One workgroup per sample row: distances, approximate first minimum, exact re-rank of the candidates.
+constexpr int BMU_KPT = 8;           // prototypes per thread held in registers (K <= 2048)
+__global__ __launch_bounds__(256) void bmu_x3_finalize_kernel(const float* __restrict__ slab, long slab_stride, int nslabs,
+                                                              const float* __restrict__ X, long ldx, const float* __restrict__ W,
+                                                              const float* __restrict__ inv_nx, const float* __restrict__ inv_nw,
+                                                              float* __restrict__ dist, int64_t* __restrict__ bmu, int K, int L,
+                                                              int* __restrict__ rerank_count) {
+    __shared__ float sb[4];
+    __shared__ int si[4];
+    __shared__ int cand[256];
+    __shared__ int ncand;
+    __shared__ double sd[4];
+    const int i = blockIdx.x, t = threadIdx.x;
+    const float rx = inv_nx[i];
+    float d[BMU_KPT];
+    float best = INFINITY;
+    int bidx = 0x7fffffff;
+    {
+        float dot[BMU_KPT];
+#pragma unroll
+        for (int u = 0; u < BMU_KPT; ++u) dot[u] = 0.f;
+        const float* p = slab + (long)i * K + t;
+        for (int s = 0; s < nslabs; ++s) {                     // fixed order s = 0, 1, ... per (i, k)
+#pragma unroll
+            for (int u = 0; u < BMU_KPT; ++u)
+                if (t + 256 * u < K) dot[u] += p[256 * u];
+            p += slab_stride;
+        }
+#pragma unroll
+        for (int u = 0; u < BMU_KPT; ++u) {
+            const int k = t + 256 * u;
+            d[u] = INFINITY;
+            if (k >= K) continue;
+            d[u] = 1.0f - dot[u] * rx * inv_nw[k];
+            if (d[u] < best || (d[u] == best && k < bidx)) { best = d[u]; bidx = k; }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bidx, o, 64);
+        if (ob < best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
+    }
+    if ((t & 63) == 0) { sb[t >> 6] = best; si[t >> 6] = bidx; }
+    if (t == 0) ncand = 0;
+    __syncthreads();
+    best = sb[0]; bidx = si[0];
+#pragma unroll
+    for (int w = 1; w < 4; ++w)
+        if (sb[w] < best || (sb[w] == best && si[w] < bidx)) { best = sb[w]; bidx = si[w]; }
+    // candidates: everything within the window of the approximate minimum (NaN never qualifies)
+    const float lim = best + BMU_WINDOW;
+#pragma unroll
+    for (int u = 0; u < BMU_KPT; ++u) {
+        const int k = t + 256 * u;
+        if (k < K && d[u] <= lim) {
+            const int slot = atomicAdd(&ncand, 1);
+            if (slot < 256) cand[slot] = k;
+        }
+    }
+    __syncthreads();
+    const int nc = ncand <= 256 ? ncand : 1;       // > 256 near-ties (degenerate input, e.g. identical prototypes): keep the approximate first minimum
+    if (nc > 1) {
+        // exact dots: fp32 products accumulated in fp64; this thread's share of x_i stays in registers
+        const f32x4* xr = reinterpret_cast<const f32x4*>(X + (long)i * ldx);
+        const int n4 = L >> 2;
+        float ebest = INFINITY;
+        int eidx = 0x7fffffff;
+        for (int c = 0; c < nc; ++c) {
+            const int k = cand[c];
+            const f32x4* wr = reinterpret_cast<const f32x4*>(W + (long)k * L);
+            double s0 = 0.0, s1 = 0.0;
+            int j = t;
+            for (; j + 256 < n4; j += 512) {
+                const f32x4 xa = xr[j], wa = wr[j], xb = xr[j + 256], wb = wr[j + 256];
+                s0 += (double)xa[0] * wa[0] + (double)xa[1] * wa[1] + (double)xa[2] * wa[2] + (double)xa[3] * wa[3];
+                s1 += (double)xb[0] * wb[0] + (double)xb[1] * wb[1] + (double)xb[2] * wb[2] + (double)xb[3] * wb[3];
+            }
+            for (; j < n4; j += 256) {
+                const f32x4 xa = xr[j], wa = wr[j];
+                s0 += (double)xa[0] * wa[0] + (double)xa[1] * wa[1] + (double)xa[2] * wa[2] + (double)xa[3] * wa[3];
+            }
+            for (int e = (n4 << 2) + t; e < L; e += 256) s0 += (double)X[(long)i * ldx + e] * W[(long)k * L + e];
+            const double ws = wave_sum_f64(s0 + s1);
+            __syncthreads();                       // sd free again
+            if ((t & 63) == 0) sd[t >> 6] = ws;
+            __syncthreads();
+            const double dotx = (sd[0] + sd[1]) + (sd[2] + sd[3]);
+            const float de = (float)(1.0 - dotx * (double)rx * (double)inv_nw[k]);
+            if (t == 0 && dist) dist[(long)i * K + k] = de;
+            if (de < ebest || (de == ebest && k < eidx)) { ebest = de; eidx = k; }
+        }
+        bidx = eidx;
+        if (t == 0 && rerank_count) atomicAdd(rerank_count, 1);
+    }
+    // the approximate distances of everything that was not re-ranked
+    if (dist) {
+#pragma unroll
+        for (int u = 0; u < BMU_KPT; ++u) {
+            const int k = t + 256 * u;
+            if (k < K && !(nc > 1 && d[u] <= lim)) dist[(long)i * K + k] = d[u];
+        }
+    }
+    if (t == 0) bmu[i] = (bidx == 0x7fffffff) ? 0 : (int64_t)bidx;
+}
+
+// tile configuration: 256 x 192 with 8 waves (one workgroup per CU) for batches of >= 192 rows, else 128 x 128 / 4 waves
+static bool bmu_x3_big(int B) { return B >= 192; }
+static int bmu_x3_tiles(int B, int K) { return bmu_x3_big(B) ? cdiv(B, 256) * cdiv(K, 192) : cdiv(B, 128) * cdiv(K, 128); }
+static int bmu_x3_splits(int B, int K, int L) {
+    const int tiles = bmu_x3_tiles(B, K), ktiles = cdiv(L, 32);
+    int s = (bmu_x3_big(B) ? 256 : 512) / tiles;     // one full round of resident workgroups
+    if (s > ktiles) s = ktiles;
+    if (s > 64) s = 64;
+    if (s < 1) s = 1;
+    const int per = cdiv(ktiles, s);
+    return cdiv(ktiles, per);
+}
+
+}  // namespace vsom
+
+using namespace vsom;
+
+extern "C" {
+
+int vsom_set_bmu_wave_specialised(int on) {
+    g_bmu_ws.store(on, std::memory_order_relaxed);
+    return VSOM_OK;
+}
+
+size_t vsom_bmu_cosine_x3_workspace_bytes(int B, int K, int L) {
+    if (B <= 0 || K <= 0 || L <= 0) return 0;
+    const size_t s = (size_t)bmu_x3_splits(B, K, L);
+    return (s * ((size_t)B * K + B + K) + 4) * sizeof(float);
+}
+
+static int x3_layout(int B, int K, int L, void* ws, BmuP& g, int& splits, int** counter) {
+    splits = bmu_x3_splits(B, K, L);
+    float* f = static_cast<float*>(ws);
+    g.slab = f; g.slab_stride = (long)B * K;
+    g.xsq = f + (size_t)splits * B * K; g.wsq = g.xsq + (size_t)splits * B;
+    *counter = reinterpret_cast<int*>(g.wsq + (size_t)splits * K);
+    return VSOM_OK;
+}
+
+/* stage 1: partial dots (three-product bf16 contraction) + partial squared norms into the workspace */
+int vsom_bmu_cosine_x3_dots(const float* X, long ldx, const float* W, int B, int K, int L, void* ws, size_t ws_bytes,
+                            vsom_stream_t stream) {
+    VSOM_REQUIRE(X && W, VSOM_EINVAL, "bmu_cosine_x3_dots: null pointer");
+    VSOM_REQUIRE(B > 0 && K > 0 && L > 0 && ldx >= L, VSOM_EINVAL, "bmu_cosine_x3_dots: bad shape B=%d K=%d L=%d ldx=%ld", B, K, L, ldx);
+    VSOM_REQUIRE(K <= 256 * BMU_KPT, VSOM_EUNSUPPORTED, "bmu_cosine_x3: more than %d prototypes", 256 * BMU_KPT);
+    VSOM_REQUIRE(L % 4 == 0 && ldx % 4 == 0 && aligned16(X) && aligned16(W), VSOM_EALIGN,
+                 "bmu_cosine_x3: rows must be 16-byte aligned (L, ldx multiples of 4)");
+    VSOM_REQUIRE(ws && ws_bytes >= vsom_bmu_cosine_x3_workspace_bytes(B, K, L) && aligned16(ws), VSOM_EWORKSPACE,
+                 "bmu_cosine_x3: workspace too small or misaligned");
+    const long xb = ((long)(B - 1) * ldx + L) * 4, wb = (long)K * L * 4;
+    VSOM_REQUIRE(xb < 0xFFFF0000L && wb < 0xFFFF0000L, VSOM_EUNSUPPORTED, "bmu_cosine_x3: operand larger than 4 GB");
+    BmuP g = {};
+    int splits; int* counter;
+    x3_layout(B, K, L, ws, g, splits, &counter);
+    g.X = X; g.ldx = ldx; g.W = W; g.B = B; g.K = K; g.L = L;
+    g.ktiles_per_split = cdiv(cdiv(L, 32), splits);
+    g.x_bytes = (unsigned)xb; g.w_bytes = (unsigned)wb;
+    const int wsm = g_bmu_ws.load(std::memory_order_relaxed);
+    if (bmu_x3_big(B) && wsm == 2)
+        hipLaunchKernelGGL((bmu_x3_ws_kernel<4, 3, 2, 2, 4, 1>), dim3(bmu_x3_tiles(B, K) * splits), dim3(512), 0, stream, g);
+    else if (bmu_x3_big(B) && wsm == 3)
+        hipLaunchKernelGGL((bmu_x3_ws_kernel<4, 3, 2, 2, 4, 2>), dim3(bmu_x3_tiles(B, K) * splits), dim3(512), 0, stream, g);
+    else if (bmu_x3_big(B) && wsm)
+        hipLaunchKernelGGL((bmu_x3_ws_kernel<4, 3, 2, 2, 4>), dim3(bmu_x3_tiles(B, K) * splits), dim3(512), 0, stream, g);
+    else if (bmu_x3_big(B)) hipLaunchKernelGGL((bmu_x3_kernel<2, 3, 4, 2>), dim3(bmu_x3_tiles(B, K) * splits), dim3(512), 0, stream, g);
+    else hipLaunchKernelGGL((bmu_x3_kernel<2, 2, 2, 2>), dim3(bmu_x3_tiles(B, K) * splits), dim3(256), 0, stream, g);
+    VSOM_LAUNCH_CHECK("bmu_x3_kernel");
+}
+
+/* stage 2: norms, distances, first minimum, exact re-rank of the near-minimum candidates.  reranked (nullable):
+   device int, incremented once per sample row that had more than one candidate */
+int vsom_bmu_cosine_x3_finalize(const float* X, long ldx, const float* W, const void* ws, size_t ws_bytes, float* dist,
+                                int64_t* bmu, float* inv_nx, float* inv_nw, int* reranked, int B, int K, int L,
+                                vsom_stream_t stream) {
+    VSOM_REQUIRE(X && W && bmu && inv_nx && inv_nw, VSOM_EINVAL, "bmu_cosine_x3_finalize: null pointer");
+    VSOM_REQUIRE(B > 0 && K > 0 && K <= 256 * BMU_KPT && L > 0 && L % 4 == 0 && ldx % 4 == 0, VSOM_EINVAL, "bmu_cosine_x3_finalize: bad shape");
+    VSOM_REQUIRE(ws && ws_bytes >= vsom_bmu_cosine_x3_workspace_bytes(B, K, L), VSOM_EWORKSPACE, "bmu_cosine_x3_finalize: workspace too small");
+    BmuP g = {};
+    int splits; int* counter;
+    x3_layout(B, K, L, const_cast<void*>(ws), g, splits, &counter);
+    hipLaunchKernelGGL(bmu_norms_kernel, dim3(cdiv(B + K, 256)), dim3(256), 0, stream, g.xsq, g.wsq, splits, B, K, inv_nx, inv_nw);
+    int rc = hip_status(hipGetLastError(), "bmu_norms_kernel");
+    if (rc) return rc;
+    hipLaunchKernelGGL(bmu_x3_finalize_kernel, dim3(B), dim3(256), 0, stream, g.slab, g.slab_stride, splits, X, ldx, W, inv_nx,
+                       inv_nw, dist, bmu, K, L, reranked);
+    VSOM_LAUNCH_CHECK("bmu_x3_finalize_kernel");
+}
+
+}  // extern "C"
