@@ -234,6 +234,9 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
 
 // One workgroup per sample row: distances, approximate first minimum, exact re-rank of the candidates.
 constexpr int BMU_KPT = 8;           // prototypes per thread held in registers (K <= 2048)
+// V4: K % 4 == 0 and 16-byte aligned slabs / dist -- a thread owns two quads of consecutive columns (16-byte accesses,
+// two slabs of loads in flight) instead of eight columns 256 apart (4-byte accesses behind a bounds branch each)
+template <bool V4>
 __global__ __launch_bounds__(256) void bmu_x3_finalize_kernel(const float* __restrict__ slab, long slab_stride, int nslabs,
                                                               const float* __restrict__ X, long ldx, const float* __restrict__ W,
                                                               const float* __restrict__ inv_nx, const float* __restrict__ inv_nw,
@@ -246,6 +249,8 @@ __global__ __launch_bounds__(256) void bmu_x3_finalize_kernel(const float* __res
     __shared__ double sd[4];
     const int i = blockIdx.x, t = threadIdx.x;
     const float rx = inv_nx[i];
+    static_assert(BMU_KPT == 8, "two quads per thread");
+    auto kcol = [&](int u) { return V4 ? 4 * t + (u & 3) + 1024 * (u >> 2) : t + 256 * u; };
     float d[BMU_KPT];
     float best = INFINITY;
     int bidx = 0x7fffffff;
@@ -253,16 +258,38 @@ __global__ __launch_bounds__(256) void bmu_x3_finalize_kernel(const float* __res
         float dot[BMU_KPT];
 #pragma unroll
         for (int u = 0; u < BMU_KPT; ++u) dot[u] = 0.f;
-        const float* p = slab + (long)i * K + t;
-        for (int s = 0; s < nslabs; ++s) {                     // fixed order s = 0, 1, ... per (i, k)
+        if constexpr (V4) {
+            const float* p = slab + (long)i * K + 4 * t;
+            const bool q0 = 4 * t < K, q1 = 4 * t + 1024 < K;
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            int s = 0;
+            for (; s + 1 < nslabs; s += 2) {                   // fixed order s = 0, 1, ... per (i, k); two slabs in flight
+                const f32x4 a0 = q0 ? *reinterpret_cast<const f32x4*>(p) : z, a1 = q1 ? *reinterpret_cast<const f32x4*>(p + 1024) : z;
+                const f32x4 b0 = q0 ? *reinterpret_cast<const f32x4*>(p + slab_stride) : z;
+                const f32x4 b1 = q1 ? *reinterpret_cast<const f32x4*>(p + slab_stride + 1024) : z;
 #pragma unroll
-            for (int u = 0; u < BMU_KPT; ++u)
-                if (t + 256 * u < K) dot[u] += p[256 * u];
-            p += slab_stride;
+                for (int e = 0; e < 4; ++e) { dot[e] += a0[e]; dot[4 + e] += a1[e]; }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { dot[e] += b0[e]; dot[4 + e] += b1[e]; }
+                p += 2 * slab_stride;
+            }
+            if (s < nslabs) {
+                const f32x4 a0 = q0 ? *reinterpret_cast<const f32x4*>(p) : z, a1 = q1 ? *reinterpret_cast<const f32x4*>(p + 1024) : z;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { dot[e] += a0[e]; dot[4 + e] += a1[e]; }
+            }
+        } else {
+            const float* p = slab + (long)i * K + t;
+            for (int s = 0; s < nslabs; ++s) {                 // fixed order s = 0, 1, ... per (i, k)
+#pragma unroll
+                for (int u = 0; u < BMU_KPT; ++u)
+                    if (t + 256 * u < K) dot[u] += p[256 * u];
+                p += slab_stride;
+            }
         }
 #pragma unroll
         for (int u = 0; u < BMU_KPT; ++u) {
-            const int k = t + 256 * u;
+            const int k = kcol(u);
             d[u] = INFINITY;
             if (k >= K) continue;
             d[u] = 1.0f - dot[u] * rx * inv_nw[k];
@@ -286,7 +313,7 @@ __global__ __launch_bounds__(256) void bmu_x3_finalize_kernel(const float* __res
     const float lim = best + BMU_WINDOW;
 #pragma unroll
     for (int u = 0; u < BMU_KPT; ++u) {
-        const int k = t + 256 * u;
+        const int k = kcol(u);
         if (k < K && d[u] <= lim) {
             const int slot = atomicAdd(&ncand, 1);
             if (slot < 256) cand[slot] = k;
@@ -331,7 +358,7 @@ __global__ __launch_bounds__(256) void bmu_x3_finalize_kernel(const float* __res
     if (dist) {
 #pragma unroll
         for (int u = 0; u < BMU_KPT; ++u) {
-            const int k = t + 256 * u;
+            const int k = kcol(u);
             if (k < K && !(nc > 1 && d[u] <= lim)) dist[(long)i * K + k] = d[u];
         }
     }
@@ -409,7 +436,12 @@ int vsom_bmu_cosine_x3_finalize(const float* X, long ldx, const float* W, const 
     hipLaunchKernelGGL(bmu_norms_kernel, dim3(cdiv(B + K, 256)), dim3(256), 0, stream, g.xsq, g.wsq, splits, B, K, inv_nx, inv_nw);
     int rc = hip_status(hipGetLastError(), "bmu_norms_kernel");
     if (rc) return rc;
-    hipLaunchKernelGGL(bmu_x3_finalize_kernel, dim3(B), dim3(256), 0, stream, g.slab, g.slab_stride, splits, X, ldx, W, inv_nx,
+    const bool v4 = K % 4 == 0 && aligned16(g.slab) && g.slab_stride % 4 == 0;
+    if (v4)
+        hipLaunchKernelGGL(bmu_x3_finalize_kernel<true>, dim3(B), dim3(256), 0, stream, g.slab, g.slab_stride, splits, X, ldx, W, inv_nx,
+                           inv_nw, dist, bmu, K, L, reranked);
+    else
+    hipLaunchKernelGGL(bmu_x3_finalize_kernel<false>, dim3(B), dim3(256), 0, stream, g.slab, g.slab_stride, splits, X, ldx, W, inv_nx,
                        inv_nw, dist, bmu, K, L, reranked);
     VSOM_LAUNCH_CHECK("bmu_x3_finalize_kernel");
 }

@@ -162,19 +162,21 @@ __global__ __launch_bounds__(256) void som_neigh_row_kernel(const float* __restr
         if (row_dot) row_dot[i] = c * (euclid ? 1.0f : rx * rx) * ((s2[0] + s2[1]) + (s2[2] + s2[3]));
     }
 }
-// col_dot[k] = c rw^2 sum_i term(i,k).  A workgroup owns 32 prototype columns; its 8 row groups each
-// take every 8th sample row (two independent accumulators) and are combined through LDS in a
-// fixed order -> bitwise reproducible.
-__global__ __launch_bounds__(256) void som_neigh_col_kernel(const float* __restrict__ dist,
-                                                            const int64_t* __restrict__ bmu,
-                                                            const float* __restrict__ grid, float inv_2T2,
-                                                            const float* __restrict__ inv_nw, float c,
-                                                            float* __restrict__ col_dot, int B, int K, int euclid,
-                                                            const float* __restrict__ h_in) {
-    __shared__ float part[8][32];
+// col_dot[k] = c rw^2 sum_i term(i,k).  A workgroup owns 32 prototype columns; its 32 row groups (16 waves) each take
+// every 32nd sample row with four independent accumulators (four rows of loads in flight: with 8 groups and two
+// accumulators the kernel was a chain of 32 dependent global-load latencies, 42 us for 3 MB) and are combined through
+// LDS in a fixed order -> bitwise reproducible.
+constexpr int NCOL_RG = 32;
+__global__ __launch_bounds__(NCOL_RG * 32) void som_neigh_col_kernel(const float* __restrict__ dist,
+                                                                     const int64_t* __restrict__ bmu,
+                                                                     const float* __restrict__ grid, float inv_2T2,
+                                                                     const float* __restrict__ inv_nw, float c,
+                                                                     float* __restrict__ col_dot, int B, int K, int euclid,
+                                                                     const float* __restrict__ h_in) {
+    __shared__ float part[NCOL_RG][32];
     const int cidx = threadIdx.x & 31, rg = threadIdx.x >> 5;
     const int k = blockIdx.x * 32 + cidx;
-    float s0 = 0.f, s1 = 0.f;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     if (k < K) {
         const float gy = h_in ? 0.f : grid[2 * k], gx = h_in ? 0.f : grid[2 * k + 1];
         auto term = [&](int i) {
@@ -190,15 +192,17 @@ __global__ __launch_bounds__(256) void som_neigh_col_kernel(const float* __restr
             return euclid ? ((d > 0.f) ? h / d : 0.f) : h * (1.0f - d);
         };
         int i = rg;
-        for (; i + 8 < B; i += 16) { s0 += term(i); s1 += term(i + 8); }
-        if (i < B) s0 += term(i);
+        for (; i + 3 * NCOL_RG < B; i += 4 * NCOL_RG) {
+            s0 += term(i); s1 += term(i + NCOL_RG); s2 += term(i + 2 * NCOL_RG); s3 += term(i + 3 * NCOL_RG);
+        }
+        for (; i < B; i += NCOL_RG) s0 += term(i);
     }
-    part[rg][cidx] = s0 + s1;
+    part[rg][cidx] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (rg == 0 && k < K) {
         float s = 0.f;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) s += part[j][cidx];
+        for (int j = 0; j < NCOL_RG; ++j) s += part[j][cidx];
         const float rw = euclid ? 1.0f : inv_nw[k];
         col_dot[k] = c * rw * rw * s;
     }
@@ -330,7 +334,7 @@ int vsom_som_neigh_loss(const float* dist, const int64_t* bmu, const float* grid
     rc = sum_partials(part, B, loss_sum, stream);
     if (rc) return rc;
     if (bwd && euclid != 2) {
-        hipLaunchKernelGGL(som_neigh_col_kernel, dim3(cdiv(K, 32)), dim3(256), 0, stream, dist, bmu, grid, inv_2T2,
+        hipLaunchKernelGGL(som_neigh_col_kernel, dim3(cdiv(K, 32)), dim3(NCOL_RG * 32), 0, stream, dist, bmu, grid, inv_2T2,
                            inv_nw, grad_scale, col_dot, B, K, euclid, (const float*)nullptr);
         rc = hip_status(hipGetLastError(), "som_neigh_col_kernel");
     }
@@ -357,7 +361,7 @@ int vsom_som_weighted_loss(const float* dist, const float* weights, const float*
     rc = sum_partials(part, B, loss_sum, stream);
     if (rc) return rc;
     if (bwd && euclid != 2) {
-        hipLaunchKernelGGL(som_neigh_col_kernel, dim3(cdiv(K, 32)), dim3(256), 0, stream, dist, (const int64_t*)nullptr,
+        hipLaunchKernelGGL(som_neigh_col_kernel, dim3(cdiv(K, 32)), dim3(NCOL_RG * 32), 0, stream, dist, (const int64_t*)nullptr,
                            (const float*)nullptr, 0.f, inv_nw, grad_scale, col_dot, B, K, euclid, weights);
         rc = hip_status(hipGetLastError(), "som_neigh_col_kernel");
     }
