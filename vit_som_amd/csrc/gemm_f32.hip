@@ -73,13 +73,12 @@ static int launch_t(GemmP& g, int splits, hipStream_t stream) {
     }
     if constexpr (A_KC && B_KC && EPI != EPI_SLAB) {
         if (fast && gemm_mode() == VSOM_GEMM_SPLIT_BF16) {
-            // 128 x 64 or 64 x 64 tiles: whichever wastes less of the last round of workgroups
-            // (256 CUs; e.g. the step's 33280-row GEMMs make 260 row tiles of 128 -- a 4-tile tail
-            // that costs a whole extra round); the small tile is charged 2 % for its extra staging.
-            auto rounds = [](long n) { return (double)((n + 255) / 256); };
-            const double c128 = rounds((long)cdiv(g.M, 128) * cdiv(g.N, 64) * splits) * 2.0;
-            const double c64 = rounds((long)cdiv(g.M, 64) * cdiv(g.N, 64) * splits) * 1.02;
-            if (c64 < c128) {
+            // 128 x 64 tiles; 64 x 64 only for problems of at most 64 rows.  (Rounds 1-2 chose between the two with a
+            // "rounds of 256 workgroups" model fitted to each GEMM running ALONE, which sent about half of the step's
+            // GEMMs to 64 x 64.  Inside the step two kernels share the chip nearly all the time (tools/timeline.py), and
+            // there the larger tile wins: every GEMM of this family on 128 x 64 is 0.3 ms per step faster, A/B on one box
+            // 11.07-11.14 -> 10.77-10.83 ms; restricting 64 x 64 to launches of < 512 or < 256 large tiles: 10.91 / 10.85.)
+            if (g.M <= 64) {
                 dim3 grid64(cdiv(g.M, 64) * cdiv(g.N, 64) * splits, 1, 1);
                 hipLaunchKernelGGL((gemm_x6_kernel<true, true, 1, 1, 2, 2, EPI>), grid64, block, 0, stream, g);
                 VSOM_LAUNCH_CHECK("gemm_x6_kernel");
@@ -263,7 +262,9 @@ static TnPlan bwd_weight_plan(int M, int N, int K) {
     }
     const int tiles = p.cfg == 1 ? (N / 192) * (K / 64) : (N / 96) * (K / 96);
     const int ktiles = cdiv(M, 32);
-    int s = (512 + tiles / 2) / tiles;                // two resident workgroups per CU
+    // ~384 workgroups: the kernel could keep 512 resident (two per CU), and alone it is fastest there; inside the step it
+    // shares the chip with the backward chain and 384 measured best (A/B per step: 256: +0.06 ms, 512: +0.05, 768 / 1024: +0.2)
+    int s = (384 + tiles / 2) / tiles;
     if (s > ktiles) s = ktiles;
     if (s < 1) s = 1;
     const int per = cdiv(ktiles, s);
