@@ -262,9 +262,9 @@ static TnPlan bwd_weight_plan(int M, int N, int K) {
     }
     const int tiles = p.cfg == 1 ? (N / 192) * (K / 64) : (N / 96) * (K / 96);
     const int ktiles = cdiv(M, 32);
-    // ~384 workgroups: the kernel could keep 512 resident (two per CU), and alone it is fastest there; inside the step it
-    // shares the chip with the backward chain and 384 measured best (A/B per step: 256: +0.06 ms, 512: +0.05, 768 / 1024: +0.2)
-    int s = (384 + tiles / 2) / tiles;
+    // two resident workgroups per CU (512): the kernel's own optimum.  Inside the step, where it shares the chip with the
+    // backward chain, 384 measured 0.02-0.06 ms per step better and 256 / 768 / 1024 worse -- not worth 10 us per launch alone
+    int s = (512 + tiles / 2) / tiles;
     if (s > ktiles) s = ktiles;
     if (s < 1) s = 1;
     const int per = cdiv(ktiles, s);
