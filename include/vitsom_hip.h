@@ -41,7 +41,8 @@ typedef struct ihipStream_t* vsom_stream_t; /* == hipStream_t */
 int vsom_version(void);
 const char* vsom_last_error_string(void);
 
-/* ------------------------------------------------------------------ Linear layers (f32 MFMA) */
+/* ------------------------------------------------------------------ Linear layers
+ * (fp32-accurate on the matrix cores: split-bf16 engine by default, exact-f32 MFMA on request -- vsom_set_gemm_mode) */
 /* Y[M,N] = X[M,K] * W[N,K]^T + bias      -- nn.Linear forward: qkv models/vit.py:30,
  * decoder_pred vit.py:234, cls_head models/vit_som.py:77.  bias may be NULL. */
 int vsom_linear_fwd(const float* X, long ldx, const float* W, const float* bias, float* Y, long ldy,
@@ -89,7 +90,9 @@ int vsom_transpose_many(const float* src_base, float* dst_base, const long long*
  *   VSOM_GEMM_SPLIT_BF16 (default) every operand split exactly into three bf16 pieces, the six
  *                        leading cross products on v_mfma_f32_32x32x16_bf16 (csrc/gemm_x6.h):
  *                        dropped terms < 2^-22 relative, 2.7x fewer matrix-core cycles.
- * The BMU distance GEMM always uses VSOM_GEMM_F32.  Process-wide; returns VSOM_EINVAL on an unknown mode. */
+ * The cosine BMU pass has its own engines: vsom_bmu_cosine_x3_* (default: two-piece split, three products, exact
+ * re-rank) and vsom_bmu_cosine_* (exact-f32 MFMA; what the host mirror uses in VSOM_GEMM_F32 mode and for the
+ * euclidean distance).  Process-wide; returns VSOM_EINVAL on an unknown mode. */
 #define VSOM_GEMM_F32 0
 #define VSOM_GEMM_SPLIT_BF16 1
 int vsom_set_gemm_mode(int mode);
@@ -136,6 +139,10 @@ int vsom_attention_fwd(const float* qkv, float* out, float* lse, int B, int N, i
 int vsom_attention_bwd(const float* qkv, const float* out, const float* dout, const float* lse,
                        float* dqkv, float* delta_ws, int B, int N, int H, int hd,
                        vsom_stream_t stream);
+/* probs[B,H,N,N] = softmax(q k^T * hd^-0.5) -- the attention maps of `return_attn=True` (vit.py:33-34,41-42), formed
+ * from qkv and the lse the forward saved (the fused kernels never materialise them).  Visualisation path only. */
+int vsom_attention_probs(const float* qkv, const float* lse, float* probs, int B, int N, int H, int hd,
+                         vsom_stream_t stream);
 /* test hook: 0 = run the short-sequence backward as two launches (dQ, then dK/dV) instead of the fused one;
    results are bit-identical either way (the GPU suite checks) */
 int vsom_set_attention_fused(int fused);
@@ -232,6 +239,24 @@ int vsom_adamw_step(float* p, const float* g, float* m, float* v, const float* w
                     float lr, float beta1, float beta2, float eps, int step, float grad_scale,
                     int adamw, vsom_stream_t stream);
 
+/* ------------------------------------------------------------------ data-parallel exchange (RCCL over xGMI) */
+/* One process per GPU, one communicator per process.  Replaces the implicit DDP gradient all-reduce of the reference
+ * (experiments/benchmarking/train_vit_som.py:44-45,86-91: DEVICES > 1 -> Lightning DDPStrategy -> NCCL).  RCCL is bound
+ * at run time (dlopen; a copy already in the process, e.g. torch.distributed's, is shared; VSOM_RCCL_PATH overrides).
+ *   vsom_comm_unique_id   rank 0 fills `id_out` (HOST memory, VSOM_COMM_ID_BYTES); the host distributes it to all ranks
+ *   vsom_comm_init        collective: every rank calls it with the same id (the current HIP device is the rank's GPU)
+ *   vsom_comm_allreduce_sum  in-place sum of buf[0..n) over the ranks, enqueued on `stream` (no host sync): the host
+ *                         mirror calls it per arena slice as the backward finishes it (ViT gradients and the [K,L]
+ *                         prototype accumulators alike); AdamW then applies grad_scale = 1/world_size
+ *   vsom_comm_info        world_size / rank of the live communicator (0 / -1 when none)
+ *   vsom_comm_destroy     releases it (idempotent) */
+#define VSOM_COMM_ID_BYTES 128
+int vsom_comm_unique_id(void* id_out);
+int vsom_comm_init(const void* unique_id, int world_size, int rank);
+int vsom_comm_allreduce_sum(float* buf, long n, vsom_stream_t stream);
+int vsom_comm_info(int* world_size, int* rank);
+int vsom_comm_destroy(void);
+
 /* ------------------------------------------------------------------ evaluation (tools/evaluation.py) */
 /* table[a[i] * nb + b[i]] += 1 for i < n  (uint64 counts, accumulates: zero it before the first
  * batch) -- the contingency matrix of calculate_purity (evaluation.py:142-145) and of the
@@ -268,6 +293,11 @@ int vsom_fill(float* p, long n, float value, vsom_stream_t stream);
 /* out[0] = ca * a[0] + cb * b[0]: the step's total loss from its two device-side sums (vit_som.py:93,98); `counter`
    (nullable, one int64 on the device) is incremented by 1 in the same launch: `self.iteration += 1` (vit_som.py:104) */
 int vsom_lincomb2(float* out, const float* a, float ca, const float* b, float cb, int64_t* counter, vsom_stream_t stream);
+/* The step's loss terms in one launch (vit_som.py:93-102): parts[0] = total = main_scale * main_sum[0] + som_coef * som_sum[0]
+   (som_coef = gamma_t / (B K): bitwise vsom_lincomb2's result), parts[1] = main_scale * main_sum[0] (reconstruction or
+   cross-entropy term), parts[2] = som_scale * som_sum[0] (the SOM term before gamma); `counter` as in vsom_lincomb2. */
+int vsom_loss_parts(float* parts, const float* main_sum, float main_scale, const float* som_sum, float som_coef,
+                    float som_scale, int64_t* counter, vsom_stream_t stream);
 /* out[i] = factor * (*scale_dev) * a[i] * b[i]  (b, scale_dev nullable -> 1): the elementwise products autograd needs
    for mean(weights * distances) (som_layer.py:137-142) with the upstream gradient as a device scalar */
 int vsom_scaled_mul(float* out, const float* a, const float* b, long n, const float* scale_dev, float factor,

@@ -190,6 +190,51 @@ def run_case(name, spec):
     print(name, "loss", float(loss), "bmu", bmu.tolist(), "min gap", float(out["fwd/top2_gap"].min()))
 
 
+def run_decoder_case(name, spec):
+    """Attribute surface other reference code reaches into: ViTAutoencoder.forward_decoder on an arbitrary
+    token tensor (tools/evaluation.py:209-222 decode_prototype; the reference's return_attn=True branch, vit.py:190-193,
+    is the one that runs), forward_features, and the attention maps of forward(return_attns=True) (vit.py:214-218,238-239)."""
+    from models.vit_som import ViTSOM
+    cfg = copy.deepcopy(spec["cfg"])
+    torch.manual_seed(0)
+    m = ViTSOM(cfg)
+    torch.set_float32_matmul_precision("highest")
+    g = torch.Generator().manual_seed(321)
+    with torch.no_grad():
+        for n_, p_ in m.named_parameters():
+            if p_.requires_grad and p_.ndim == 1:
+                p_.add_(0.1 * torch.randn(p_.shape, generator=g))
+    d = cfg["data"]
+    vit = m.vit
+    n, E = vit.patch_embed.num_patches, cfg["hyperparameters"]["vit"]["emb_dim"]
+    x = torch.randn(3, d["num_channels"], d["input_size"], d["input_size"], generator=g)
+    tokens = torch.randn(2, n + 1, E, generator=g)
+    tokens[:, 0] = 0.0                                  # decode_prototype's zero CLS placeholder
+    out = {"param/" + k: v.detach().clone().numpy() for k, v in m.state_dict().items()}
+    out["x"], out["tokens"] = x.numpy(), tokens.numpy()
+    m.eval()
+    with torch.no_grad():
+        patches, attns = vit.forward_decoder(tokens, return_attn=True)
+        out["dec/patches"] = patches.numpy()
+        out["dec/recon"] = vit.unpatchify(patches).numpy()
+        for i, a_ in enumerate(attns):
+            out[f"dec/attn{i}"] = a_.numpy()
+        cls, patch_tokens, recon, eattns = vit(x, return_attns=True)
+        out["fwd/cls"], out["fwd/patches"], out["fwd/recon"] = cls.numpy(), patch_tokens.numpy(), recon.numpy()
+        for i, a_ in enumerate(eattns):
+            out[f"fwd/attn{i}"] = a_.numpy()
+        fcls, fattns = vit.forward_features(x, return_attns=True)
+        out["ff/cls"] = fcls.numpy()
+        out["ff/n_attn"] = np.int64(len(fattns))
+    import json
+    out["config_json"] = np.array(json.dumps(cfg))
+    np.savez_compressed(os.path.join(OUT, "ref_decoder_" + name[4:] + ".npz"), **out)
+    print("ref_decoder_" + name[4:], "patches", tuple(patches.shape), "attn maps", len(attns), "+", len(eattns))
+
+
+DECODER_CASES = ["ref_cluster_tiny", "ref_mnistlike_tiny", "ref_cls_tiny"]
+
+
 def main():
     _install_stand_ins()
     os.makedirs(OUT, exist_ok=True)
@@ -197,6 +242,9 @@ def main():
     for name, spec in CASES.items():
         if not only or name in only:
             run_case(name, spec)
+    for name in DECODER_CASES:
+        if not only or ("ref_decoder_" + name[4:]) in only:
+            run_decoder_case(name, CASES[name])
     if only and "ref_lr_schedule" not in only:
         return
     # scheduler known answers from the reference's own LambdaLR lambda (vit_som.py:160)

@@ -265,6 +265,45 @@ def vit_forward(P: Params, x: torch.Tensor, d: Dims):
     return cls_out, patches, unpatchify(pred, d.p)                            # vit.py:236
 
 
+def attention_map(P: Params, pre: str, x: torch.Tensor, heads: int) -> torch.Tensor:
+    """The [B, heads, N, N] softmax probabilities Attention.forward returns with return_attn=True (vit.py:33-34,41-42);
+    x is the block's LayerNorm-ed input."""
+    B, N, C = x.shape
+    hd = C // heads
+    qkv = F.linear(x, P[f"{pre}.qkv.weight"], P[f"{pre}.qkv.bias"]).reshape(B, N, 3, heads, hd).permute(2, 0, 3, 1, 4)
+    return ((qkv[0] @ qkv[1].transpose(-2, -1)) * (hd ** -0.5)).softmax(dim=-1)
+
+
+def _blocks_with_maps(P: Params, prefix: str, depth: int, t: torch.Tensor, heads: int):
+    maps = []
+    for i in range(depth):
+        pre = f"{prefix}.{i}"
+        h = F.layer_norm(t, (t.shape[-1],), P[f"{pre}.norm1.weight"], P[f"{pre}.norm1.bias"], 1e-6)
+        maps.append(attention_map(P, f"{pre}.attn", h, heads))
+        t = block(P, pre, t, heads)
+    return t, maps
+
+
+def vit_forward_features(P: Params, x: torch.Tensor, d: Dims):
+    """ViTAutoencoder.forward_features(return_attns=True), vit.py:155-179 -> (cls_token_out, [attention maps])."""
+    t = patch_embed(P, x, d.p) + P["vit.pos_embed"][:, 1:, :]
+    cls = P["vit.cls_token"] + P["vit.pos_embed"][:, :1, :]
+    t = torch.cat((cls.expand(t.shape[0], -1, -1), t), dim=1)
+    t, maps = _blocks_with_maps(P, "vit.blocks", d.depth, t, d.H)
+    t = F.layer_norm(t, (d.E,), P["vit.norm.weight"], P["vit.norm.bias"], 1e-6)
+    return t[:, 0], maps
+
+
+def vit_forward_decoder(P: Params, tokens: torch.Tensor, d: Dims):
+    """ViTAutoencoder.forward_decoder(return_attn=True), vit.py:182-200 -> (decoded_patches [B,n,p*p*C], [maps]) for an
+    arbitrary token tensor [B, n+1, E] (caller: tools/evaluation.py:209-222)."""
+    dec = F.linear(tokens, P["vit.decoder_embed.weight"], P["vit.decoder_embed.bias"])      # vit.py:186
+    dec = dec + P["vit.decoder_pos_embed"]                                                  # vit.py:187
+    dec, maps = _blocks_with_maps(P, "vit.decoder_blocks", d.ddepth, dec, d.DH)             # vit.py:189-195
+    dec = F.layer_norm(dec, (d.DE,), P["vit.decoder_norm.weight"], P["vit.decoder_norm.bias"], 1e-6)
+    return F.linear(dec, P["vit.decoder_pred.weight"], P["vit.decoder_pred.bias"])[:, 1:, :], maps   # vit.py:197
+
+
 # --------------------------------------------------------------------------------------
 # A5-A7: SOM layer  (models/som_layer.py:83-152)
 # --------------------------------------------------------------------------------------

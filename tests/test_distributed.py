@@ -152,6 +152,107 @@ def test_two_ranks_equal_single_process_on_concatenated_batch(tmp_path):
     assert torch.allclose(dp["params"], ref, atol=0.25 * dp["lr"])      # within a quarter of one Adam step
 
 
+@pytest.mark.gpu
+def test_vsom_comm_rccl_one_rank_bucketed_exchange_keeps_the_trajectory():
+    """The library's own RCCL communicator (vsom_comm_init / _allreduce_sum / _destroy behind the C-ABI): on a 1-rank
+    communicator a sum all-reduce is the identity, so the whole bucketed exchange (prototype accumulators first, decoder,
+    encoder block groups, remainder -- each enqueued on the exchange stream behind the events of the streams that wrote
+    it) with the N > 1 branches forced must leave the 6-step trajectory bit-identical to the plain single-GPU one."""
+    import vit_som_amd
+    from oracle.gen_golden import make_config
+    from vit_som_amd import ops
+    cfg = make_config(3, 32, 4, 192, 6, 3, 96, 2, (12, 12), 0, 64)
+    g = torch.Generator().manual_seed(1)
+    x = torch.rand(64, 3, 32, 32, generator=g).cuda()
+    y = torch.zeros(64, dtype=torch.int64).cuda()
+
+    def run(use_comm):
+        torch.manual_seed(0)
+        m = vit_som_amd.ViTSOM(copy.deepcopy(cfg), device="cuda:0")
+        m.set_schedule(50000, 1000)
+        calls = []
+        if use_comm:
+            m.set_distributed(1, 0, backend="rccl")
+            assert ops.comm_info() == (1, 0)
+            m.world_size = 2                          # force the N > 1 branches; AdamW's 1/world is undone below
+            orig = ops.comm_allreduce_sum
+
+            def counted(t):
+                calls.append(t.numel())
+                return orig(t)
+            ops.comm_allreduce_sum = counted
+        try:
+            (opt,), _ = m.configure_optimizers()
+            losses = []
+            for _ in range(6):
+                losses.append(m.train_step_fused(x, y))
+                if use_comm:
+                    m.allreduce_gradients()
+                    m.world_size = 1                  # 1-rank sum: no averaging to undo in AdamW
+                opt.step()
+                if use_comm:
+                    m.world_size = 2
+            torch.cuda.synchronize()
+        finally:
+            if use_comm:
+                ops.comm_allreduce_sum = orig
+        return [float(v) for v in losses], m.arena.params.clone(), calls, m.arena.numel
+
+    l0, p0, _, _ = run(False)
+    try:
+        l1, p1, calls, numel = run(True)
+    finally:
+        ops.comm_destroy()
+    assert ops.comm_info() == (0, -1)
+    per_step = len(calls) // 6
+    assert per_step >= 4 and sum(calls) == 6 * numel, (per_step, sum(calls), numel)      # every float reduced exactly once per step
+    assert l0 == l1 and torch.equal(p0, p1)
+
+
+def _train_worker(rank, world, port, out, mode):
+    import vit_som_amd.train as T
+    os.environ.update(WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      VSOM_DIST_BACKEND="gloo")
+    z, cfg = load_golden("ref_cls_tiny" if mode == "cls" else "ref_cluster_tiny")
+    cfg = copy.deepcopy(cfg)
+    cfg["hyperparameters"]["total_epochs"] = 2
+    logs = []
+    res = T.main(cfg, n_runs=1, make_loaders=lambda c, r, w: T.synthetic_loaders(c, r, w, n_train=96, n_val=24, n_test=24),
+                 model_states_dir=os.path.join(os.path.dirname(out), "states"), log=logs.append)
+    torch.save({k: v for k, v in res.items() if k not in ("run_duration", "inference_time")}, out + f".{rank}")
+    if dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["cls", "cluster"])
+def test_train_driver_two_ranks_report_whole_set_metrics(tmp_path, mode):
+    """vit_som_amd.train.main at world_size 2 (two ranks on the one GPU of the test box, gloo transport): every rank
+    evaluates the reloaded checkpoint on ITS shard, the contingency tables are summed over the ranks, so both ranks
+    report the same metrics -- those of the whole set, as the single-process run on the same data does."""
+    out = str(tmp_path / "m.pt")
+    mp.spawn(_train_worker, args=(2, _free_port(), out, mode), nprocs=2, join=True)
+    r0, r1 = torch.load(out + ".0"), torch.load(out + ".1")
+    assert r0 == r1, (r0, r1)
+    keys = ("accuracy", "precision", "recall", "f1") if mode == "cls" else ("purity", "nmi")
+    assert all(len(r0[k]) == 1 and 0.0 <= r0[k][0] <= 1.0 for k in keys)
+    # single process on the same samples: per-rank batch b at world 2 == global batch 2 b (reference batch_size is per rank)
+    import vit_som_amd.train as T
+    z, cfg = load_golden("ref_cls_tiny" if mode == "cls" else "ref_cluster_tiny")
+    cfg = copy.deepcopy(cfg)
+    cfg["hyperparameters"]["total_epochs"] = 2
+    cfg["hyperparameters"]["batch_size"] *= 2                     # global batch; lr follows batch_size in the reference formula
+    cfg["hyperparameters"]["optimizer"]["lr"] /= 2
+    for k_ in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        os.environ.pop(k_, None)
+    single = T.main(cfg, n_runs=1, make_loaders=lambda c, r, w: T.synthetic_loaders(c, r, w, n_train=96, n_val=24, n_test=24),
+                    model_states_dir=str(tmp_path / "states1"), log=lambda *_: None)
+    # same samples per step, same schedules; only the summation order differs (a near-tie may move a sample or two)
+    for k in keys:
+        assert abs(single[k][0] - r0[k][0]) <= 0.1, (k, single[k], r0[k])
+
+
 def test_bench_launcher_stops_the_other_ranks_when_one_dies(tmp_path):
     """bench.py --gpus N as its own launcher: a rank that exits non-zero ends the job (the others are terminated, not
     left waiting in the rendezvous) and its code is the launcher's."""

@@ -202,6 +202,15 @@ def test_stream_level_concurrency_is_bitwise_identical():
     from vit_som_amd.tuning import hooks
     cfg = make_config(3, 32, 4, 192, 4, 3, 96, 2, (12, 12), 0, 96)
     finals = []
+    try:
+        _run_switch_combinations(cfg, finals, hooks, ops, vit_som_amd)
+    finally:
+        hooks.reset()
+        ops.set_attention_fused(True)
+    assert all(torch.equal(finals[0], f) for f in finals[1:])
+
+
+def _run_switch_combinations(cfg, finals, hooks, ops, vit_som_amd):
     for side, split, nblk, fused in (("0", "0", None, True), ("1", "1", None, True), ("1", "0", None, False), ("0", "1", 2, True),
                                      ("1", "1", 1, False)):
         hooks.set(side_stream=side == "1", fwd_split=split == "1", fwd_split_blocks=nblk)
@@ -221,9 +230,6 @@ def test_stream_level_concurrency_is_bitwise_identical():
         assert (m.vit.__dict__.get("_fwd_side") is not None) == (split == "1")
         assert split == "0" or m.vit._fwd_side is m._side_stream          # the second chain borrows the backward's side stream
         finals.append(m.arena.params.clone())
-    hooks.reset()
-    ops.set_attention_fused(True)
-    assert all(torch.equal(finals[0], f) for f in finals[1:])
 
 
 def test_use_reduced_cls_token_som():
@@ -481,3 +487,127 @@ def test_iteration_buffer_advances_with_the_training_step_only():
     assert int(model.iteration) == 3 and model.state_dict()["iteration"].item() == 3
     model.train_step_fused(x, y)
     assert int(model.iteration) == 4
+
+
+DECODER_CASES = ["ref_decoder_cluster_tiny", "ref_decoder_mnistlike_tiny", "ref_decoder_cls_tiny"]
+
+
+@pytest.mark.parametrize("name", DECODER_CASES)
+def test_forward_decoder_features_and_attention_maps_match_reference_golden(name):
+    """ViTAutoencoder.forward_decoder on an arbitrary token tensor (vit.py:182-200; caller tools/evaluation.py:209-222),
+    forward_features (vit.py:155-179) and the attention maps of return_attn(s)=True (vit.py:41-42) against outputs of the
+    reference itself."""
+    z, cfg = load_golden(name)
+    m = build(cfg, golden_params(z))
+    vit = m.vit
+    tokens, x = torch.from_numpy(z["tokens"]).to(DEV), torch.from_numpy(z["x"]).to(DEV)
+    patches, none = vit.forward_decoder(tokens, return_attn=False)
+    assert none is None and patches.shape == z["dec/patches"].shape
+    assert torch.allclose(patches.cpu(), torch.from_numpy(z["dec/patches"]), atol=2e-5)
+    assert torch.allclose(vit.unpatchify(patches).cpu(), torch.from_numpy(z["dec/recon"]), atol=2e-5)
+    p2, maps = vit.forward_decoder(tokens, return_attn=True)
+    assert torch.equal(p2, patches) and len(maps) == len(vit.decoder_blocks)
+    for i, a_ in enumerate(maps):
+        ref = torch.from_numpy(z[f"dec/attn{i}"])
+        assert a_.shape == ref.shape and torch.allclose(a_.cpu(), ref, atol=2e-6)
+        assert torch.allclose(a_.sum(-1).cpu(), torch.ones(ref.shape[:-1]), atol=1e-5)
+    cls, nothing = vit.forward_features(x)
+    assert nothing is None and torch.allclose(cls.cpu(), torch.from_numpy(z["ff/cls"]), atol=2e-5)
+    cls2, emaps = vit.forward_features(x, return_attns=True)
+    assert torch.equal(cls2, cls) and len(emaps) == int(z["ff/n_attn"])
+    out = vit(x, return_attns=True)
+    assert len(out) == 4 and torch.allclose(out[2].cpu(), torch.from_numpy(z["fwd/recon"]), atol=2e-5)
+    for i, (a_, b_) in enumerate(zip(emaps, out[3])):
+        ref = torch.from_numpy(z[f"fwd/attn{i}"])
+        assert torch.allclose(a_.cpu(), ref, atol=2e-6) and torch.equal(a_, b_)
+    # decoder fed with the encoder's own tokens reproduces forward()'s reconstruction bit for bit (same kernels)
+    cls3, ptok, recon = vit(x)
+    full = torch.cat([cls3.unsqueeze(1), ptok], dim=1)
+    again, _ = vit.forward_decoder(full)
+    assert torch.equal(vit.unpatchify(again), recon)
+    # a second cached batch size did not evict the first one's buffers
+    assert set(vit._acts) == {x.shape[0], tokens.shape[0]} or x.shape[0] == tokens.shape[0]
+    with pytest.raises(ValueError):
+        vit.forward_decoder(tokens[:, :-1])
+
+
+def test_decoder_and_features_are_differentiable_on_their_own():
+    """forward_decoder / forward_features under torch autograd against the oracle under CPU autograd: parameter
+    gradients and the gradient w.r.t. the token tensor forward_decoder was fed."""
+    from oracle import vitsom_oracle as O
+    z, cfg = load_golden("ref_decoder_mnistlike_tiny")
+    P = golden_params(z)
+    d = O.Dims(cfg)
+    tokens, x = torch.from_numpy(z["tokens"]), torch.from_numpy(z["x"])
+    wts = torch.randn(tuple(z["dec/patches"].shape), generator=torch.Generator().manual_seed(9))
+    leaves = {k: v.clone().requires_grad_(True) for k, v in P.items() if k in O.trainable_keys(P)}
+    Pl = dict(P); Pl.update(leaves)
+    tk = tokens.clone().requires_grad_(True)
+    ref = (O.vit_forward_decoder(Pl, tk, d)[0] * wts).sum() + O.vit_forward_features(Pl, x, d)[0].pow(2).sum()
+    ref.backward()
+    m = build(cfg, P)
+    m.zero_grad(set_to_none=True)
+    tg = tokens.to(DEV).requires_grad_(True)
+    l1 = (m.vit.forward_decoder(tg)[0] * wts.to(DEV)).sum()
+    l1.backward()                                  # before the next forward: the activation buffers are reused
+    g_dec = {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+    m.zero_grad(set_to_none=True)
+    l2 = m.vit.forward_features(x.to(DEV))[0].pow(2).sum()
+    l2.backward()
+    assert abs(float(l1) + float(l2) - float(ref)) < 1e-4 * max(1.0, abs(float(ref)))
+    assert rel_err(tg.grad.cpu(), tk.grad) < 1e-4
+    worst = 0.0
+    for n, p in m.named_parameters():
+        if not n.startswith("vit.") or not p.requires_grad:
+            continue
+        g = (p.grad if p.grad is not None else 0) + g_dec.get(n, 0)
+        r = leaves[n].grad
+        if r is None or float(r.abs().max()) == 0.0:
+            assert float(torch.as_tensor(g).abs().max()) == 0.0, n
+            continue
+        worst = max(worst, rel_err(g.cpu(), r))
+    assert worst < 1e-4, worst
+
+
+def test_stale_or_repeated_backward_is_refused():
+    """The activation buffers are reused per batch size: a backward after they were rewritten (by ANY forward: no_grad
+    calls and the fused training step included) raises instead of returning gradients of the wrong batch; one
+    training_step gives one backward; an input image that requires grad is refused."""
+    z, cfg = load_golden("ref_cluster_tiny")
+    m = build(cfg, golden_params(z))
+    m.set_schedule(int(z["n_train"]), int(z["est_steps"]))
+    x, y = torch.from_numpy(z["x"]).to(DEV), torch.from_numpy(z["y"]).to(DEV)
+    out = m.vit(x)
+    with torch.no_grad():
+        m.vit(x)                                   # rewrites the buffers without autograd
+    with pytest.raises(RuntimeError, match="rewritten"):
+        out[0].sum().backward()
+    out = m.vit(x)
+    m.train_step_fused(x, y)                       # the fused step writes the same buffers
+    with pytest.raises(RuntimeError, match="rewritten"):
+        out[2].sum().backward()
+    loss = m.training_step((x, y), 0)
+    loss.backward(retain_graph=True)
+    with pytest.raises(RuntimeError, match="twice"):
+        loss.backward()
+    with pytest.raises(RuntimeError, match="input image"):
+        m.vit(x.clone().requires_grad_(True))
+
+
+def test_loss_parts_are_plain_tensors_with_a_lifetime():
+    """model._last is an ordinary dict of tensors ('total', 'main', 'som'; vit_som.py:95-102 logs them): .get / `in` /
+    iteration see every key, and a step's values stay valid while the next steps run."""
+    z, cfg = load_golden("ref_cluster_tiny")
+    m = build(cfg, golden_params(z))
+    m.set_schedule(int(z["n_train"]), int(z["est_steps"]))
+    x, y = torch.from_numpy(z["x"]).to(DEV), torch.from_numpy(z["y"]).to(DEV)
+    l0 = m.train_step_fused(x, y)
+    first = dict(m._last)
+    assert type(m._last) is dict and {"total", "main", "som", "gamma_t", "T"} <= set(first) and m._last.get("main") is not None
+    v0 = {k: float(first[k]) for k in ("total", "main", "som")}
+    assert abs(v0["total"] - (v0["main"] + first["gamma_t"] * v0["som"])) < 1e-6 and abs(v0["total"] - float(z["train/loss"])) < 2e-5
+    x1, y1 = torch.from_numpy(z["x1"]).to(DEV), torch.from_numpy(z["y1"]).to(DEV)
+    for _ in range(3):
+        m.train_step_fused(x1, y1)
+        m.validation_step((x1, y1), 0)
+    assert {k: float(first[k]) for k in ("total", "main", "som")} == v0 and float(l0) == v0["total"]

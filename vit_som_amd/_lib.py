@@ -46,6 +46,12 @@ SIGNATURES = {
     "vsom_attention_fwd": (C.c_int, [c_fp, c_fp, c_fp, C.c_int, C.c_int, C.c_int, C.c_int, c_stream]),
     "vsom_attention_bwd": (C.c_int, [c_fp] * 6 + [C.c_int] * 4 + [c_stream]),
     "vsom_set_attention_fused": (C.c_int, [C.c_int]),
+    "vsom_attention_probs": (C.c_int, [c_fp, c_fp, c_fp, C.c_int, C.c_int, C.c_int, C.c_int, c_stream]),
+    "vsom_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "vsom_comm_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
+    "vsom_comm_allreduce_sum": (C.c_int, [c_fp, C.c_long, c_stream]),
+    "vsom_comm_info": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "vsom_comm_destroy": (C.c_int, []),
     "vsom_row_inv_norm": (C.c_int, [c_fp, C.c_long, C.c_int, C.c_int, C.c_float, c_fp, c_stream]),
     "vsom_row_sqnorm": (C.c_int, [c_fp, C.c_long, C.c_int, C.c_int, c_fp, c_stream]),
     "vsom_bmu_euclid_fwd": (C.c_int, [c_fp, C.c_long, c_fp, c_fp, c_fp, c_fp, c_fp, C.c_int, C.c_int, C.c_int, c_fp,
@@ -84,6 +90,7 @@ SIGNATURES = {
     "vsom_som_weighted_loss": (C.c_int, [c_fp, c_fp, c_fp, c_fp, C.c_float, c_fp, c_fp, c_fp, c_fp, C.c_int, C.c_int, C.c_int,
                                          c_fp, C.c_size_t, c_stream]),
     "vsom_lincomb2": (C.c_int, [c_fp, c_fp, C.c_float, c_fp, C.c_float, C.c_void_p, c_stream]),
+    "vsom_loss_parts": (C.c_int, [c_fp, c_fp, C.c_float, c_fp, C.c_float, C.c_float, C.c_void_p, c_stream]),
     "vsom_scale_by": (C.c_int, [c_fp, C.c_long, c_fp, c_stream]),
     "vsom_reduce_slabs": (C.c_int, [c_fp, C.c_long, C.c_int, c_fp, C.c_long, c_stream]),
 }

@@ -1210,6 +1210,26 @@ static int launch_bwd(const float* qkv, const float* out, const float* dout, con
                         : launch_bwd_t<HDP, false>(qkv, out, dout, lse, dqkv, delta, B, N, H, hd, st);
 }
 
+
+// ------------------------------------------------------------------ attention maps (return_attn=True, vit.py:33-34,41-42)
+// probs[b,h,i,j] = exp(scale * q_i . k_j - lse[b,h,i]) from the qkv buffer and the log-sum-exp the forward saved: the
+// softmax probabilities the fused kernels never write.  Visualisation path only (tools/evaluation.py); plain VALU.
+__global__ __launch_bounds__(256) void attn_probs_kernel(const float* __restrict__ qkv, const float* __restrict__ lse,
+                                                         float* __restrict__ probs, int N, int H, int hd, float scale) {
+    const int bh = blockIdx.x, b = bh / H, h = bh % H;
+    const int E3 = 3 * H * hd;
+    const float* q0 = qkv + (long)b * N * E3 + h * hd;
+    const float* k0 = q0 + H * hd;
+    for (long idx = (long)blockIdx.y * 256 + threadIdx.x; idx < (long)N * N; idx += (long)gridDim.y * 256) {
+        const int i = (int)(idx / N), j = (int)(idx % N);
+        const float* q = q0 + (long)i * E3;
+        const float* k = k0 + (long)j * E3;
+        float s = 0.f;
+        for (int d = 0; d < hd; ++d) s = fmaf(q[d], k[d], s);
+        probs[((long)bh * N + i) * N + j] = __expf(s * scale - lse[(long)bh * N + i]);
+    }
+}
+
 static int attn_check(const char* who, int B, int N, int H, int hd, int* hdp) {
     VSOM_REQUIRE(B > 0 && N > 0 && H > 0 && hd > 0, VSOM_EINVAL, "%s: bad shape B=%d N=%d H=%d hd=%d", who, B, N, H, hd);
     *hdp = attn_hdp(hd);
@@ -1260,6 +1280,14 @@ int vsom_attention_bwd(const float* qkv, const float* out, const float* dout, co
         case 32: return launch_bwd<32>(qkv, out, dout, lse, dqkv, delta_ws, B, N, H, hd, stream);
         default: return launch_bwd<64>(qkv, out, dout, lse, dqkv, delta_ws, B, N, H, hd, stream);
     }
+}
+
+int vsom_attention_probs(const float* qkv, const float* lse, float* probs, int B, int N, int H, int hd, vsom_stream_t stream) {
+    VSOM_REQUIRE(qkv && lse && probs, VSOM_EINVAL, "attention_probs: null pointer");
+    VSOM_REQUIRE(B > 0 && N > 0 && H > 0 && hd > 0, VSOM_EINVAL, "attention_probs: bad shape B=%d N=%d H=%d hd=%d", B, N, H, hd);
+    const int by = cdiv((long)N * N, 256) < 64 ? cdiv((long)N * N, 256) : 64;
+    hipLaunchKernelGGL(attn_probs_kernel, dim3(B * H, by), dim3(256), 0, stream, qkv, lse, probs, N, H, hd, 1.0f / sqrtf((float)hd));
+    VSOM_LAUNCH_CHECK("attn_probs_kernel");
 }
 
 }  // extern "C"

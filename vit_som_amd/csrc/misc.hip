@@ -204,6 +204,18 @@ __global__ void lincomb2_kernel(float* __restrict__ out, const float* __restrict
     }
 }
 
+// parts[0] = total = main_scale * main_sum + som_coef * som_sum ; parts[1] = main ; parts[2] = som_scale * som_sum
+__global__ void loss_parts_kernel(float* __restrict__ parts, const float* __restrict__ main_sum, float main_scale,
+                                  const float* __restrict__ som_sum, float som_coef, float som_scale, long long* __restrict__ counter) {
+    if (threadIdx.x == 0) {
+        const float m = main_scale * main_sum[0];
+        parts[0] = fmaf(som_coef, som_sum[0], m);
+        parts[1] = m;
+        parts[2] = som_scale * som_sum[0];
+        if (counter) counter[0] += 1;
+    }
+}
+
 // batched 32x32-tile transpose through LDS; blockIdx.y = tensor, blockIdx.x = tile (surplus tiles exit)
 __global__ __launch_bounds__(256) void transpose_many_kernel(const float* __restrict__ src_base, float* __restrict__ dst_base,
                                                              const long long* __restrict__ table) {
@@ -272,6 +284,14 @@ int vsom_lincomb2(float* out, const float* a, float ca, const float* b, float cb
     VSOM_REQUIRE(out && a && b, VSOM_EINVAL, "lincomb2: null pointer");
     hipLaunchKernelGGL(lincomb2_kernel, dim3(1), dim3(64), 0, stream, out, a, ca, b, cb, reinterpret_cast<long long*>(counter));
     VSOM_LAUNCH_CHECK("lincomb2_kernel");
+}
+
+int vsom_loss_parts(float* parts, const float* main_sum, float main_scale, const float* som_sum, float som_coef, float som_scale,
+                    int64_t* counter, vsom_stream_t stream) {
+    VSOM_REQUIRE(parts && main_sum && som_sum, VSOM_EINVAL, "loss_parts: null pointer");
+    hipLaunchKernelGGL(loss_parts_kernel, dim3(1), dim3(64), 0, stream, parts, main_sum, main_scale, som_sum, som_coef, som_scale,
+                       reinterpret_cast<long long*>(counter));
+    VSOM_LAUNCH_CHECK("loss_parts_kernel");
 }
 
 int vsom_transpose_many(const float* src_base, float* dst_base, const long long* table, int count, int max_rows,

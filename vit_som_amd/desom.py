@@ -207,6 +207,7 @@ class DESOM(_ArenaOwner, _Base):
         else:
             total = recon + g * som
         self._ctx = (x, a, s)
+        self._forward_id, self._seeds_consumed = self._forward_id + 1, False
         self._last = {"recon": recon, "som": som, "total": total}
         return total
 

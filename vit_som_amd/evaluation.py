@@ -30,9 +30,18 @@ class _Table:
             t[:, :self.table.shape[1]] = self.table
             self.table = t
 
-    def numpy(self):
-        if int(self.bad.item()):
-            raise ValueError(f"{int(self.bad.item())} label/prediction values fell outside the contingency table")
+    def numpy(self, world_size=1):
+        """The table on the host -- summed over the ranks first when every rank folded its own shard of the data
+        (one all-reduce of the integer table: every rank then reports the metrics of the WHOLE set)."""
+        if world_size > 1:
+            import torch.distributed as dist
+            both = torch.cat([self.table.view(-1), self.bad.view(-1).long()])
+            dist.all_reduce(both)
+            self.table, self.bad = both[:-1].view_as(self.table), both[-1:].int()
+        nbad = int(self.bad.item())
+        if nbad:
+            raise ValueError(f"{nbad} label/prediction values fell outside the contingency table "
+                             f"({self.table.shape[0]} x {self.table.shape[1]}); pass num_labels= for larger label sets")
         return self.table.cpu().numpy()
 
 
@@ -90,27 +99,28 @@ def calculate_purity(y_trues, y_preds):
     return purity_from_table(t.numpy())
 
 
+def _world(model):
+    return int(getattr(model, "world_size", 1))
+
+
 def evaluate_clustering(model, config, dataloader, num_labels=None):
-    """evaluation.py:18-52 -> (purity, nmi, inference_time) from the model's native BMU assignments."""
+    """evaluation.py:18-52 -> (purity, nmi, inference_time) from the model's native BMU assignments.  No host
+    synchronisation inside the loop: labels outside [0, num_labels) are counted on the device and reported once at the
+    end (num_labels defaults to max(data.num_classes, 256)).  With model.world_size > 1 every rank folds its shard and
+    the tables are summed, so all ranks return the metrics of the whole set."""
     model.eval()
     d = config["data"]
     C, S = d["num_channels"], d["input_size"]
     K = model.som_layer.n_prototypes
     dev = model.arena.device
-    table, start = None, time.time()
+    L = int(num_labels) if num_labels else max(int(d.get("num_classes", 0)), 256)
+    table, start = _Table(K, L, dev), time.time()
     for x, y in dataloader:
         x = x.to(dev, non_blocking=True).reshape(-1, C, S, S)
         y = y.to(dev, non_blocking=True)
-        if y.numel() and int(y.min()) < 0:
-            raise ValueError("evaluate_clustering: negative label in this batch")
-        L = int(num_labels) if num_labels else max(int(d.get("num_classes", 0)), int(y.max()) + 1 if y.numel() else 1, 1)
-        if table is None:
-            table = _Table(K, L, dev)
-        elif not num_labels:
-            table.grow_columns(L)              # a later batch may carry a larger label than any seen so far
         bmu, _ = model.predict(x)
         table.add(bmu, y.view(-1))
-    w = table.numpy()
+    w = table.numpy(_world(model))
     purity, nmi = purity_from_table(w), nmi_from_table(w)
     inference_time = time.time() - start
     print(f"Purity: {purity:.3f}, NMI: {nmi:.3f}, Inference Time: {inference_time:.3f}")
@@ -118,7 +128,8 @@ def evaluate_clustering(model, config, dataloader, num_labels=None):
 
 
 def evaluate_classification(model, config, dataloader):
-    """evaluation.py:93-128 -> (accuracy, precision, recall, f1, inference_time) (macro averages)."""
+    """evaluation.py:93-128 -> (accuracy, precision, recall, f1, inference_time) (macro averages); summed over the
+    ranks like evaluate_clustering."""
     model.eval()
     d = config["data"]
     C, S, ncls = d["num_channels"], d["input_size"], d["num_classes"]
@@ -132,7 +143,7 @@ def evaluate_classification(model, config, dataloader):
             pred = torch.empty(logits.shape[0], dtype=torch.int64, device=dev)
         ops.argmax_rows(logits, pred)
         table.add(y.view(-1), pred)                       # cm[true, pred]
-    acc, precision, recall, f1 = classification_from_table(table.numpy())
+    acc, precision, recall, f1 = classification_from_table(table.numpy(_world(model)))
     inference_time = time.time() - start
     print(f"Accuracy: {acc:.3f}, Precision: {precision:.3f}, Recall: {recall:.3f}, F1-score: {f1:.3f}, Inference Time: {inference_time:.3f}")
     return acc, precision, recall, f1, inference_time

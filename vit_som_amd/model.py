@@ -136,18 +136,7 @@ class _Acts:
     pass
 
 
-class _LossParts(dict):
-    """The step's loss terms for logging: 'total' is the tensor the step computed; 'main' (reconstruction or
-    cross-entropy) and 'som' are formed from the device-side sums only when somebody asks for them."""
-
-    def __init__(self, main_sum, main_scale, som_sum, som_scale, total, gamma_t, T):
-        super().__init__(total=total, gamma_t=gamma_t, T=T)
-        self._lazy = {"main": (main_sum, main_scale), "som": (som_sum, som_scale)}
-
-    def __missing__(self, key):
-        buf, scale = self._lazy[key]
-        self[key] = buf[0] * scale
-        return self[key]
+_LOSS_RING = 16     # the loss terms of a step stay readable until this many further steps have run
 
 
 # ------------------------------------------------------------------------------------ ViT autoencoder
@@ -254,7 +243,10 @@ class ViTAutoencoder(nn.Module):
         a.delta = f(B * max(self.num_heads, self.decoder_num_heads) * N)
         a.dpred = f(T, pd)
         a.d_xe = f(T, E)
-        self._acts = {B: a}
+        a.version = 0            # bumped whenever the activation buffers are rewritten (staleness guard of the autograd bridges)
+        # at most two batch sizes stay allocated (the training batch and, e.g., decode_prototype's batch of one)
+        keep = list(self._acts.items())[-1:]
+        self._acts = dict(keep + [(B, a)])
         return a
 
     # -- forward ------------------------------------------------------------------------------
@@ -272,6 +264,7 @@ class ViTAutoencoder(nn.Module):
     def _encode(self, x: torch.Tensor, a: _Acts):
         E = self.embed_dim
         p = self.patch_embed.patch_size[0]
+        a.version += 1
         ops.patch_embed_fwd(x, self.patch_embed.proj.weight.view(E, -1), self.patch_embed.proj.bias, self.pos_embed[0],
                             self.cls_token.view(E), a.tok0, a.xp, p)
         cur = a.tok0
@@ -342,29 +335,50 @@ class ViTAutoencoder(nn.Module):
             raise ValueError(f"expected input [B,{self.in_chans},{self.img_size},{self.img_size}], got {tuple(x.shape)}")
         return x.contiguous().float()
 
-    @torch.no_grad()
+    def _attention_maps(self, blocks, layers, a: _Acts):
+        """[B, heads, N, N] softmax probabilities of every block (vit.py:33-34,41-42), formed from the saved qkv / lse."""
+        out = []
+        for blk, L in zip(blocks, layers):
+            probs = torch.empty(a.B, blk.heads, a.N, a.N, dtype=torch.float32, device=a.device)
+            ops.attention_probs(L.qkv, L.lse, probs, a.B, a.N, blk.heads, blk.dim // blk.heads)
+            out.append(probs)
+        return out
+
+    def _wants_grad(self, *inputs):
+        return torch.is_grad_enabled() and (any(p.requires_grad for _, p in _trainable_order(self))
+                                            or any(t.requires_grad for t in inputs))
+
     def forward_features(self, x, return_attns=False):
-        """vit.py:155-179 -> (cls_token_out, None)."""
-        if return_attns:
-            raise NotImplementedError("attention maps are never materialised by the fused kernels")
+        """vit.py:155-179 -> (cls_token_out [B,E], attns | None); differentiable w.r.t. the encoder parameters
+        under autograd (``_VitForwardFn`` in features mode)."""
         x = self._check_input(x)
-        a = self._buffers_for(x.shape[0], x.device)
-        xe = self._encode(x, a).view(a.B, a.N, self.embed_dim)
-        return xe[:, 0].clone(), None
+        if self._wants_grad(x):
+            cls = _VitForwardFn.apply(x, self, "features", *[p for _, p in _trainable_order(self)])
+            a = self._acts[x.shape[0]]
+        else:
+            with torch.no_grad():
+                a = self._buffers_for(x.shape[0], x.device)
+                cls = self._encode(x, a).view(a.B, a.N, self.embed_dim)[:, 0].clone()
+        with torch.no_grad():
+            attns = self._attention_maps(self.blocks, a.enc, a) if return_attns else None
+        return cls, attns
 
     def forward(self, x, return_attns=False):
-        """vit.py:202-240 -> (cls_token_out [B,E], patch_tokens_out [B,n,E], recon_img [B,C,S,S]).  With autograd
-        enabled the three outputs are differentiable w.r.t. every trainable parameter (``_VitForwardFn``: the
-        stand-alone use of the sub-module; the fused training step of ViTSOM does not go through here)."""
-        if return_attns:
-            raise NotImplementedError("attention maps are never materialised by the fused kernels")
+        """vit.py:202-240 -> (cls_token_out [B,E], patch_tokens_out [B,n,E], recon_img [B,C,S,S]) (+ the encoder's
+        attention maps as a fourth element when return_attns, vit.py:238-239).  With autograd enabled the three
+        outputs are differentiable w.r.t. every trainable parameter (``_VitForwardFn``: the stand-alone use of the
+        sub-module; the fused training step of ViTSOM does not go through here)."""
         x = self._check_input(x)
-        if torch.is_grad_enabled():
-            params = [p for _, p in _trainable_order(self)]
-            if any(p.requires_grad for p in params):
-                return _VitForwardFn.apply(x, self, *params)
-        with torch.no_grad():
-            return self._forward_impl(x)
+        if self._wants_grad(x):
+            out = _VitForwardFn.apply(x, self, "full", *[p for _, p in _trainable_order(self)])
+        else:
+            with torch.no_grad():
+                out = self._forward_impl(x)
+        if return_attns:
+            with torch.no_grad():
+                a = self._acts[x.shape[0]]
+                return tuple(out) + (self._attention_maps(self.blocks, a.enc, a),)
+        return out
 
     def _forward_impl(self, x):
         a = self._buffers_for(x.shape[0], x.device)
@@ -374,6 +388,36 @@ class ViTAutoencoder(nn.Module):
         scratch1 = torch.empty(1, dtype=torch.float32, device=x.device)
         ops.l1_unpatchify(a.pred, x, scratch1, recon=recon, p=self.patch_embed.patch_size[0])
         return xe[:, 0].clone(), xe[:, 1:].clone(), recon
+
+    def forward_decoder(self, x, return_attn=False):
+        """vit.py:182-200 -> (decoded_patches [B,n,p*p*C], attns | None): decoder_embed -> + decoder_pos_embed -> decoder
+        blocks -> decoder_norm -> decoder_pred[:, 1:] on an ARBITRARY token tensor x [B,n+1,E] (tools/evaluation.py:209-222
+        feeds a prototype behind a zero CLS row).  The reference's return_attn=False branch assigns the block's
+        (x, attn) tuple to `decoded` (vit.py:195) and fails at decoder_norm; this is what it means.  Differentiable
+        w.r.t. the decoder parameters and x under autograd."""
+        n, E = self.patch_embed.num_patches, self.embed_dim
+        if x.dim() != 3 or x.shape[1] != n + 1 or x.shape[2] != E:
+            raise ValueError(f"forward_decoder: expected tokens [B,{n + 1},{E}], got {tuple(x.shape)}")
+        if not x.is_cuda:
+            raise ValueError("forward_decoder: input must live on the MI355X (there is no CPU path)")
+        x = x.float()
+        if self._wants_grad(x):
+            patches = _VitDecoderFn.apply(x, self, *[p for _, p in _trainable_order(self)])
+            a = self._acts[x.shape[0]]
+        else:
+            with torch.no_grad():
+                a = self._decode_tokens(x)
+                patches = a.pred.view(a.B, a.N, -1)[:, 1:].clone()
+        with torch.no_grad():
+            attns = self._attention_maps(self.decoder_blocks, a.dec, a) if return_attn else None
+        return patches, attns
+
+    def _decode_tokens(self, x):
+        a = self._buffers_for(x.shape[0], x.device)
+        a.version += 1
+        a.xe.view(a.B, a.N, self.embed_dim).copy_(x)
+        self._decode(a)
+        return a
 
     # -- backward -----------------------------------------------------------------------------
     @staticmethod
@@ -504,28 +548,40 @@ class ViTAutoencoder(nn.Module):
 
 
 # ------------------------------------------------------------------------------------ per-module autograd
+def _stale(vit, B, version):
+    a = vit._acts.get(B)
+    if a is None or a.version != version:
+        raise RuntimeError("ViTAutoencoder: backward() after the activation buffers of this batch size were rewritten "
+                           "(another forward / training_step / validation_step ran in between); call backward first")
+    return a
+
+
 class _VitForwardFn(torch.autograd.Function):
-    """ViTAutoencoder.forward for stand-alone use under autograd (models/vit.py:202-240): forward = the HIP forward
-    kernels; backward = the same HIP backward kernels the fused step uses, fed with the upstream gradients of
-    (cls, patches, recon).  The gradient w.r.t. the input image is not produced (nothing on the path needs it)."""
+    """ViTAutoencoder.forward / forward_features for stand-alone use under autograd (models/vit.py:155-179,202-240):
+    forward = the HIP forward kernels; backward = the same HIP backward kernels the fused step uses, fed with the
+    upstream gradients of (cls, patches, recon) -- or of cls alone in "features" mode.  The gradient w.r.t. the input
+    IMAGE is not produced (nothing on the path needs it): an input that requires grad is refused."""
 
     @staticmethod
-    def forward(ctx, x, vit, *params):
-        ctx.vit, ctx.B = vit, x.shape[0]
+    def forward(ctx, x, vit, mode, *params):
+        if x.requires_grad:
+            raise RuntimeError("ViTAutoencoder: the gradient w.r.t. the input image is not implemented")
+        ctx.vit, ctx.B, ctx.mode = vit, x.shape[0], mode
         with torch.no_grad():
-            out = vit._forward_impl(x)
-        ctx.version = vit.__dict__["_fwd_version"] = vit.__dict__.get("_fwd_version", 0) + 1
+            if mode == "features":
+                a = vit._buffers_for(x.shape[0], x.device)
+                out = vit._encode(x, a).view(a.B, a.N, vit.embed_dim)[:, 0].clone()
+            else:
+                out = vit._forward_impl(x)
+        ctx.version = vit._acts[ctx.B].version
         return out
 
     @staticmethod
-    def backward(ctx, g_cls, g_patches, g_recon):
+    def backward(ctx, g_cls, g_patches=None, g_recon=None):
         vit = ctx.vit
-        if vit.__dict__.get("_fwd_version") != ctx.version:
-            raise RuntimeError("ViTAutoencoder: backward() after another forward() -- the activation buffers are reused "
-                               "per batch size; call backward before the next forward")
+        a = _stale(vit, ctx.B, ctx.version)
         named = _trainable_order(vit)
         with torch.no_grad():
-            a = vit._buffers_for(ctx.B, named[0][1].device)
             grads = {n: torch.zeros_like(p) for n, p in named}
             G = grads.__getitem__
             E, N, B = vit.embed_dim, a.N, a.B
@@ -546,7 +602,39 @@ class _VitForwardFn(torch.autograd.Function):
                 vit._encoder_bwd(a, G)
             finally:
                 vit._side = side
-        return (None, None) + tuple(grads[n] for n, _ in named)
+        return (None, None, None) + tuple(grads[n] for n, _ in named)
+
+
+class _VitDecoderFn(torch.autograd.Function):
+    """ViTAutoencoder.forward_decoder under autograd (models/vit.py:182-200): gradients to the decoder parameters and
+    to the token tensor it was fed."""
+
+    @staticmethod
+    def forward(ctx, x, vit, *params):
+        ctx.vit, ctx.B = vit, x.shape[0]
+        with torch.no_grad():
+            a = vit._decode_tokens(x)
+            out = a.pred.view(a.B, a.N, -1)[:, 1:].clone()
+        ctx.version = a.version
+        return out
+
+    @staticmethod
+    def backward(ctx, g_patches):
+        vit = ctx.vit
+        a = _stale(vit, ctx.B, ctx.version)
+        named = _trainable_order(vit)
+        with torch.no_grad():
+            grads = {n: torch.zeros_like(p) for n, p in named}
+            side, vit._side = vit._side, None
+            try:
+                dp = a.dpred.view(a.B, a.N, -1)
+                dp[:, 0].zero_()
+                dp[:, 1:].copy_(g_patches.float())
+                vit._decoder_bwd(a, grads.__getitem__)
+            finally:
+                vit._side = side
+            gx = a.d_xe.view(a.B, a.N, vit.embed_dim).clone()
+        return (gx, None) + tuple(grads[n] for n, _ in named)
 
 
 class _SomDistancesFn(torch.autograd.Function):
@@ -855,15 +943,40 @@ class _StepLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, anchor, model, x, y, gamma_t, T):
         ctx.model = model
-        return model._forward_losses(x, y, gamma_t, T, want_grad=True).clone()
+        out = model._forward_losses(x, y, gamma_t, T, want_grad=True).clone()
+        ctx.forward_id = model._forward_id
+        return out
 
     @staticmethod
     def backward(ctx, gout):
         m = ctx.model
+        if ctx.forward_id != m._forward_id or m._seeds_consumed:
+            raise RuntimeError("ViTSOM: backward() called twice for one training_step (or after a later forward): the "
+                               "step's buffers and gradient seeds are single-use; gradient accumulation is not supported")
+        m._seeds_consumed = True
         m._scale_seeds(gout)               # 1.0 under a plain loss.backward()
         m._backward()
         m._expose_grads()
         return None, None, None, None, None, None
+
+
+def init_vsom_comm(world_size: int, rank: int, unique_id: Optional[bytes] = None):
+    """One RCCL communicator per process behind the C-ABI (vsom_comm_init).  The unique id comes from rank 0; with no
+    `unique_id` given it travels over the torch.distributed process group the launcher set up (host-side plumbing)."""
+    w, r = ops.comm_info()
+    if w == world_size and r == rank:
+        return
+    if w != 0:
+        ops.comm_destroy()
+    if unique_id is None:
+        if world_size == 1:
+            unique_id = ops.comm_unique_id()
+        else:
+            import torch.distributed as dist
+            box = [ops.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            unique_id = box[0]
+    ops.comm_init(unique_id, world_size, rank)
 
 
 # ------------------------------------------------------------------------------------ arena owner
@@ -875,6 +988,7 @@ class _ArenaOwner:
     arena: Optional[ParamArena] = None
     world_size, rank = 1, 0
     _grads_reduced = False
+    _forward_id, _seeds_consumed = 0, False      # one backward per forward of the fused step (_StepLoss)
 
     def _default_weight_decay(self, name: str, p) -> float:
         return 0.0
@@ -925,9 +1039,24 @@ class _ArenaOwner:
         for n, p in self._named_trainable():
             p.grad = self._grad_views[n]
 
-    def set_distributed(self, world_size: int, rank: int = 0):
+    _use_vsom_comm = False
+
+    def set_distributed(self, world_size: int, rank: int = 0, backend: Optional[str] = None):
+        """backend: "rccl" = the library's own communicator (vsom_comm_*; the default on the GPU unless torch.distributed
+        runs on gloo), "torch" = torch.distributed's all_reduce (gloo on CPU tensors, or its "nccl" = RCCL)."""
         self.world_size, self.rank = int(world_size), int(rank)
         self.som_layer._world_size = int(world_size)
+        if backend is None:
+            backend = "torch"
+            if self.world_size > 1 and self.arena is not None and self.arena.grads.is_cuda:
+                import torch.distributed as dist
+                if dist.is_available() and dist.is_initialized() and dist.get_backend() != "gloo":
+                    backend = "rccl"
+        if backend not in ("rccl", "torch"):
+            raise ValueError(f"set_distributed: unknown backend {backend!r}")
+        self._use_vsom_comm = backend == "rccl"
+        if self._use_vsom_comm:
+            init_vsom_comm(self.world_size, self.rank)
 
     # -- data-parallel exchange: sum all-reduce over the gradient arena, in pieces -----------------
     # Each piece is a contiguous arena slice whose gradients are final at a known point of the backward
@@ -941,7 +1070,14 @@ class _ArenaOwner:
         return self.world_size > 1 and hooks.overlap_allreduce
 
     def _exchange_reset(self):
-        self._works, self._started = [], []
+        """Forget the pieces of the previous exchange.  Pieces still in flight (a backward pass whose gradients were
+        never consumed by allreduce_gradients() / optimizer.step()) are waited for first: the new backward is about
+        to overwrite the arena slices they are reducing."""
+        for w in getattr(self, "_works", ()):
+            w.wait()
+        if getattr(self, "_comm_dirty", False) and self.arena is not None and self.arena.grads.is_cuda:
+            torch.cuda.current_stream().wait_stream(self._comm)
+        self._works, self._started, self._comm_dirty = [], [], False
 
     def _arena_span(self, first: str, last: str):
         """[lo, hi) of the arena slice from parameter `first` through parameter `last` (padded)."""
@@ -961,11 +1097,16 @@ class _ArenaOwner:
                 comm = self._comm = torch.cuda.Stream(device=g.device)
             for ev in after:
                 comm.wait_event(ev)
-            with torch.cuda.stream(comm):
-                work = dist.all_reduce(g[lo:hi], op=dist.ReduceOp.SUM, async_op=True)
+            if self._use_vsom_comm:
+                # the library's own RCCL communicator (vsom_comm_*): the collective is enqueued on `comm` like a kernel
+                with on_stream(comm):
+                    ops.comm_allreduce_sum(g[lo:hi])
+                self._comm_dirty = True
+            else:
+                with torch.cuda.stream(comm):
+                    self._works.append(dist.all_reduce(g[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
         else:
-            work = dist.all_reduce(g[lo:hi], op=dist.ReduceOp.SUM, async_op=True)
-        self._works.append(work)
+            self._works.append(dist.all_reduce(g[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
         self._started.append((lo, hi))
 
     def _reduce_early(self, lo: int, hi: int, streams=()):
@@ -999,9 +1140,7 @@ class _ArenaOwner:
             if lo > pos:
                 self._reduce_async(pos, lo, evs)
             pos = max(pos, hi)
-        for w in self._works:
-            w.wait()                            # nccl: the current stream waits; gloo: the host does
-        self._exchange_reset()
+        self._exchange_reset()                  # torch "nccl" / vsom_comm: the current stream waits; gloo: the host does
 
     def broadcast_parameters(self, src: int = 0):
         """Replicas are built from the same seed; this makes it explicit (DDP broadcasts at construction)."""
@@ -1045,6 +1184,7 @@ class ViTSOM(_ArenaOwner, _Base):
         self._est_steps: Optional[int] = None
         self.world_size, self.rank = 1, 0
         self._grads_reduced = False
+        self._forward_id, self._seeds_consumed = 0, False
         self._last: Dict[str, torch.Tensor] = {}
         self.arena: Optional[ParamArena] = None
         if device is None:
@@ -1174,10 +1314,12 @@ class ViTSOM(_ArenaOwner, _Base):
         x, a, s = self._run_forward(x, need_decoder=not self.classification)
         B, K = a.B, self.som_layer.n_prototypes
         self._ctx = (x, a, s)
+        self._forward_id, self._seeds_consumed = self._forward_id + 1, False
         dev = x.device
         if not hasattr(a, "main_sum"):
             a.main_sum = torch.empty(1, dtype=torch.float32, device=dev)
-            a.total = torch.empty(1, dtype=torch.float32, device=dev)
+            a.loss_ring = torch.zeros(_LOSS_RING, 4, dtype=torch.float32, device=dev)
+            a.loss_slot = 0
         c = gamma_t / (B * K)
         if want_grad:
             ops.som_neigh_loss(s.dist, s.bmu, self.som_layer.grid_positions, T, s.loss_sum, inv_nx=s.inx, inv_nw=s.inw,
@@ -1197,11 +1339,16 @@ class ViTSOM(_ArenaOwner, _Base):
             ops.l1_unpatchify(a.pred, x, a.main_sum, dpred=a.dpred if want_grad else None, grad_scale=1.0 / x.numel(),
                               p=self.vit.patch_embed.patch_size[0])
             main_scale = 1.0 / x.numel()
-        # total = main + gamma_t * som from the two device-side sums, in one tiny kernel that also advances the
-        # `iteration` buffer of a training step (vit_som.py:104): no ATen kernel in the step
-        ops.lincomb2(a.total, a.main_sum, main_scale, s.loss_sum, gamma_t / (B * K), counter=self.iteration if want_grad else None)
-        self._last = _LossParts(a.main_sum, main_scale, s.loss_sum, 1.0 / (B * K), a.total[0], gamma_t, T)
-        return a.total[0]
+        # total = main + gamma_t * som (and the two terms by themselves, for logging) from the two device-side sums, in one
+        # tiny kernel that also advances the `iteration` buffer of a training step (vit_som.py:104): no ATen kernel in
+        # the step.  The three values land in their own slot of a small ring, so `_last` and the returned loss stay
+        # valid for the next _LOSS_RING - 1 steps (plain tensors: .get / `in` / iteration / ** all see them).
+        a.loss_slot = (a.loss_slot + 1) % _LOSS_RING
+        parts = a.loss_ring[a.loss_slot]
+        ops.loss_parts(parts, a.main_sum, main_scale, s.loss_sum, gamma_t / (B * K), 1.0 / (B * K),
+                       counter=self.iteration if want_grad else None)
+        self._last = {"total": parts[0], "main": parts[1], "som": parts[2], "gamma_t": gamma_t, "T": T}
+        return parts[0]
 
     def _ensure_streams(self, device):
         """The two extra HIP streams of the step (kept to two: a process has few hardware queues)."""
@@ -1301,7 +1448,11 @@ class ViTSOM(_ArenaOwner, _Base):
                 som_backward(gX, False)
             if "som" in buckets:
                 self._reduce_early(*buckets["som"], streams=[side])
-            som_done = self.vit._event()
+            # a dedicated event: its wait is deferred to the end of the decoder backward, by which time a pooled
+            # (round-robin) event could have been re-recorded for something else (deep decoders)
+            som_done = self.__dict__.get("_som_done_ev")
+            if som_done is None:
+                som_done = self.__dict__["_som_done_ev"] = torch.cuda.Event()
             som_done.record(side)
             self.vit._decoder_bwd(a, Gv, self._WT, before_dxe=lambda: main.wait_event(som_done))
             if "decoder" in buckets:
@@ -1332,6 +1483,10 @@ class ViTSOM(_ArenaOwner, _Base):
             self._anchor = torch.zeros((), device=self.arena.device, requires_grad=True)
         total = _StepLoss.apply(self._anchor, self, x, y, gamma_t, T)
         self._advance()
+        if _HAVE_PL and getattr(self, "_trainer", None) is not None:          # vit_som.py:91,95-102
+            main = "train/cls_loss" if self.classification else "train/recon_loss"
+            self._log("hp/gamma", gamma_t)
+            self._log({main: self._last["main"], "train/som_loss": self._last["som"], "train/total_loss": self._last["total"]})
         return total
 
     def train_step_fused(self, x, y):
@@ -1354,6 +1509,12 @@ class ViTSOM(_ArenaOwner, _Base):
         if self.classification:
             a = self._ctx[1]
             self._last["acc"] = (a.logits.argmax(dim=-1) == y.view(-1)).float().mean()
+        if _HAVE_PL and getattr(self, "_trainer", None) is not None:          # vit_som.py:116-123
+            main = "val/cls_loss" if self.classification else "val/recon_loss"
+            logs = {main: self._last["main"], "val/som_loss": self._last["som"], "val/total_loss": self._last["total"]}
+            if self.classification:
+                logs["val/accuracy"] = self._last["acc"]
+            self._log(logs)
         return total.clone()
 
     def configure_optimizers(self):

@@ -238,6 +238,14 @@ def attention_bwd(qkv, out, dout, lse, dqkv, delta, B, N, H, hd):
     return dqkv
 
 
+def attention_probs(qkv, lse, probs, B, N, H, hd):
+    """probs[B,H,N,N] = softmax(q k^T / sqrt(hd)) from qkv and the saved log-sum-exp (attention maps, vit.py:41-42)."""
+    assert qkv.is_contiguous() and lse.is_contiguous() and probs.is_contiguous() and probs.shape == (B, H, N, N)
+    _f32(qkv, "qkv"); _f32(probs, "probs")
+    check(lib.vsom_attention_probs(ptr(qkv), ptr(lse), ptr(probs), B, N, H, hd, stream()), "vsom_attention_probs")
+    return probs
+
+
 # ---------------------------------------------------------------- SOM
 def row_inv_norm(x, out, eps=1e-12):
     rows, cols = x.shape
@@ -420,6 +428,17 @@ def lincomb2(out, a, ca, b, cb, counter=None):
     return out
 
 
+def loss_parts(parts, main_sum, main_scale, som_sum, som_coef, som_scale, counter=None):
+    """parts[0:3] = (total, main term, SOM term) of the step; `counter` += 1 in the same launch (see lincomb2)."""
+    if counter is not None:
+        assert counter.dtype == torch.int64 and counter.is_cuda and counter.numel() == 1
+    _f32(parts, "parts")
+    assert parts.numel() >= 3 and parts.is_contiguous()
+    check(lib.vsom_loss_parts(ptr(parts), ptr(main_sum), float(main_scale), ptr(som_sum), float(som_coef), float(som_scale),
+                              None if counter is None else counter.data_ptr(), stream()), "vsom_loss_parts")
+    return parts
+
+
 def scale_by(t, scale_dev):
     """t *= scale_dev[0] (device scalar, no host sync)."""
     _f32(t, "t"); _f32(scale_dev, "scale")
@@ -450,3 +469,42 @@ def argmax_rows(x, out):
     assert out.dtype == torch.int64
     check(lib.vsom_argmax_rows(ptr(x), _rows(x), rows, cols, ptr(out), stream()), "vsom_argmax_rows")
     return out
+
+
+# ---------------------------------------------------------------- data-parallel exchange (RCCL)
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id() -> bytes:
+    """Rank 0: a fresh RCCL unique id (host bytes) to hand to every rank's comm_init."""
+    import ctypes
+    buf = ctypes.create_string_buffer(COMM_ID_BYTES)
+    check(lib.vsom_comm_unique_id(buf), "vsom_comm_unique_id")
+    return buf.raw
+
+
+def comm_init(unique_id: bytes, world_size: int, rank: int):
+    """Collective: build this process's communicator (the current HIP device is this rank's GPU)."""
+    import ctypes
+    assert len(unique_id) == COMM_ID_BYTES
+    buf = ctypes.create_string_buffer(unique_id, COMM_ID_BYTES)
+    check(lib.vsom_comm_init(buf, int(world_size), int(rank)), "vsom_comm_init")
+
+
+def comm_info():
+    import ctypes
+    w, r = ctypes.c_int(), ctypes.c_int()
+    check(lib.vsom_comm_info(ctypes.byref(w), ctypes.byref(r)), "vsom_comm_info")
+    return w.value, r.value
+
+
+def comm_allreduce_sum(t):
+    """In-place sum of `t` over the ranks, enqueued on the launch stream (no host sync)."""
+    _f32(t, "t")
+    assert t.is_contiguous()
+    check(lib.vsom_comm_allreduce_sum(ptr(t), t.numel(), stream()), "vsom_comm_allreduce_sum")
+    return t
+
+
+def comm_destroy():
+    check(lib.vsom_comm_destroy(), "vsom_comm_destroy")

@@ -27,20 +27,30 @@ from .model import ViTSOM
 
 
 def load_config(config_path="./configs/config.yaml"):
-    """tools/utils.py:14-26 (DATASET_NAME environment override included)."""
-    with open(config_path, "r") as f:
-        config = yaml.safe_load(f)
-    dataset_name = os.getenv("DATASET_NAME")
-    if dataset_name:
-        config["data"]["dataset"] = dataset_name
-    return config
+    """The YAML config as a nested dict; a non-empty DATASET_NAME in the environment replaces data.dataset
+    (behaviour of tools/utils.py:14-26)."""
+    with open(config_path) as fh:
+        cfg = yaml.safe_load(fh)
+    cfg["data"]["dataset"] = os.environ.get("DATASET_NAME") or cfg["data"]["dataset"]
+    return cfg
 
 
 def clear_directory(directory):
-    """train_vit_som.py:19-25."""
-    if os.path.exists(directory):
-        shutil.rmtree(directory)
-    os.makedirs(directory)
+    """Start every run from an empty checkpoint directory (behaviour of train_vit_som.py:19-25)."""
+    shutil.rmtree(directory, ignore_errors=True)
+    os.makedirs(directory, exist_ok=True)
+
+
+def _report(all_metrics, n_runs, dataset_name, log):
+    """Mean (std) over the runs, in the reference's output format (train_vit_som.py:118-130)."""
+    log(f"\n--- Aggregated Results Across {n_runs} Runs for {dataset_name} ---")
+    timed = {"run_duration", "inference_time"}
+    for key, scores in all_metrics.items():
+        if not scores:
+            continue
+        mean, std = float(np.mean(scores)), float(np.std(scores))
+        label = key.capitalize()
+        log(f"Avg {label} (Std): {mean:.2f}s ({std:.2f}s)" if key in timed else f"{label} Mean (Std): {mean:.4f} ({std:.4f})")
 
 
 class TensorLoader:
@@ -157,24 +167,26 @@ def main(config, n_runs=5, max_epochs=None, make_loaders=synthetic_loaders, mode
         torch.cuda.synchronize()
         run_duration = time.time() - start
         log(f"Run {run + 1} duration: {run_duration:.2f} seconds")
+        # Final evaluation: every rank folds ITS shard of the loader into the contingency table and the tables are summed
+        # over the ranks (evaluation.py), so all ranks hold the metrics of the whole set.
         if use_validation:
             acc, prec, rec, f1, inf_t = evaluate_classification(model, config, test_loader)
             for k, v in (("accuracy", acc), ("precision", prec), ("recall", rec), ("f1", f1)):
                 all_metrics[k].append(v)
         else:
-            final_model = ViTSOM.load_from_checkpoint(out["last_model_path"], config=config) if rank == 0 else model
+            # the reference reloads the last checkpoint (train_vit_som.py:111): rank 0 wrote it, every rank loads that file
+            path = os.path.join(model_states_dir, "last.ckpt")
+            if world > 1:
+                torch.distributed.barrier()
+            final_model = ViTSOM.load_from_checkpoint(path, config=config)
+            final_model.set_distributed(world, rank, backend="torch")
             purity, nmi, inf_t = evaluate_clustering(final_model, config, train_loader)
             all_metrics["purity"].append(purity)
             all_metrics["nmi"].append(nmi)
         all_metrics["run_duration"].append(run_duration)
         all_metrics["inference_time"].append(inf_t)
     if n_runs > 1:
-        log(f"\\n--- Aggregated Results Across {n_runs} Runs for {dataset_name} ---")
-        for key, scores in all_metrics.items():
-            if scores:
-                mean, std = float(np.mean(scores)), float(np.std(scores))
-                log(f"Avg {key.capitalize()} (Std): {mean:.2f}s ({std:.2f}s)" if key in ("run_duration", "inference_time")
-                    else f"{key.capitalize()} Mean (Std): {mean:.4f} ({std:.4f})")
+        _report(all_metrics, n_runs, dataset_name, log)
     return all_metrics
 
 
