@@ -335,6 +335,54 @@ def test_full_size_c3_step_properties():
     assert abs(float(m._last["som"]) - float((h * s.dist.double()).mean())) < 1e-7
 
 
+@pytest.mark.parametrize("name,chans,img,p,E,depth,heads,DE,map_size,B", [
+    ("c1", 1, 28, 2, 16, 4, 2, 4, (24, 24), 128),         # BASELINE configs[0]: MNIST shapes, N = 197 tokens, L = 3136
+    ("c2", 3, 32, 4, 192, 12, 3, 96, (24, 24), 512)])     # BASELINE configs[1]: CIFAR-10 shapes, 24x24 SOM, batch 512
+def test_full_size_c1_c2_step_properties(name, chans, img, p, E, depth, heads, DE, map_size, B):
+    """BASELINE c1 and c2 at their FULL size (depth, map, batch) through the same size-independent properties as c3:
+    determinism + bitwise linearity of the backward in the loss seed, BMU == first argmin of the step's own distances,
+    distances against fp64 on the device, BMU == fp64 argmin on every row whose winner is unambiguous in fp32, the SOM
+    loss recomputed in fp64, and no row of the cosine pass left to an un-re-ranked tie."""
+    import vit_som_amd
+    from oracle.gen_golden import make_config
+    cfg = make_config(chans, img, p, E, depth, heads, DE, 2, map_size, 0, B, gamma=0.01, Tmax=4.0, Tmin=0.1)
+    g = torch.Generator().manual_seed(17)
+    x = torch.randn(B, chans, img, img, generator=g).to(DEV)
+    y = torch.zeros(B, dtype=torch.int64, device=DEV)
+    arenas, losses = [], []
+    for rep in range(2):
+        torch.manual_seed(0)
+        m = vit_som_amd.ViTSOM(copy.deepcopy(cfg), device=DEV)
+        m.set_schedule(60000, 9000)
+        m._it = 800
+        loss = m.training_step((x, y), 0)
+        (loss * (2.0 if rep else 1.0)).backward()
+        arenas.append(m.arena.grads.clone())
+        losses.append(float(loss.detach()))
+    # deterministic AND linear in the seed, bit for bit wherever doubling is exact (gradients of prototypes far from every
+    # BMU reach the fp32 denormal range, ~1e-41, where a factor of two rounds -- and sums that contain such addends)
+    assert losses[0] == losses[1]
+    big = arenas[0].abs() > 1e-24                       # no denormal addend can reach the last bit of these
+    assert int(big.sum()) > 0.5 * arenas[0].numel() and torch.equal(arenas[1][big], 2.0 * arenas[0][big])
+    assert float((arenas[1] - 2.0 * arenas[0])[~big].abs().max()) < 1e-30
+    a, s = m._ctx[1], m._ctx[2]
+    assert s.dist.shape == (B, map_size[0] * map_size[1]) and torch.equal(s.bmu, s.dist.argmin(dim=1))
+    X = m._som_input(a).double()
+    W = m.som_layer.prototypes.detach().double()
+    ref = 1.0 - torch.nn.functional.normalize(X, dim=1) @ torch.nn.functional.normalize(W, dim=1).T
+    assert float((s.dist.double() - ref).abs().max()) < 2e-6
+    gap = ref.topk(2, dim=1, largest=False).values
+    sure = (gap[:, 1] - gap[:, 0]) > 4e-6
+    assert int(sure.sum()) > 0.75 * B and torch.equal(s.bmu[sure], ref.argmin(dim=1)[sure])
+    T = float(m.som_layer.current_temperature)
+    pos = m.som_layer.grid_positions.double()
+    h = torch.exp(-(pos[None, :, :] - pos[s.bmu][:, None, :]).pow(2).sum(-1) / (2 * T * T))
+    assert abs(float(m._last["som"]) - float((h * s.dist.double()).mean())) < 1e-7
+    for n_, p_ in m.named_parameters():
+        if p_.requires_grad:
+            assert torch.isfinite(p_.grad).all(), n_
+
+
 @pytest.mark.parametrize("name,img,classes,map_size,B", [("c4", 32, 100, (4, 4), 128), ("c5", 64, 200, (40, 40), 256)])
 def test_full_size_c4_c5_step_properties(name, img, classes, map_size, B):
     """BASELINE c4 (CIFAR-100 shapes, 4x4 SOM, 1024 global = 128 per GPU) and c5 (Tiny-ImageNet 64x64 -> 257
@@ -363,6 +411,9 @@ def test_full_size_c4_c5_step_properties(name, img, classes, map_size, B):
     W = m.som_layer.prototypes.detach().double()
     ref = 1.0 - torch.nn.functional.normalize(X, dim=1) @ torch.nn.functional.normalize(W, dim=1).T
     assert float((s.dist.double() - ref).abs().max()) < 2e-6
+    gap = ref.topk(2, dim=1, largest=False).values
+    sure = (gap[:, 1] - gap[:, 0]) > 4e-6                             # rows whose fp64 winner is unambiguous in fp32
+    assert int(sure.sum()) > 0.75 * B and torch.equal(s.bmu[sure], ref.argmin(dim=1)[sure])
     cls_tok = m._cls_view(a.xe, a).double()
     logits_ref = cls_tok @ m.cls_head.weight.detach().double().T + m.cls_head.bias.detach().double()
     assert float((a.logits.double() - logits_ref).abs().max()) < 1e-5

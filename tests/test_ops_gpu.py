@@ -330,7 +330,7 @@ def test_bmu_cosine(ops, O, B, K, L):
 
 
 @pytest.mark.parametrize("B,K,L", [(70, 15, 256), (64, 576, 3136), (128, 16, 12288), (33, 100, 48), (5, 7, 20), (512, 1600, 12288),
-                                    (130, 2048, 192)])
+                                    (130, 2048, 192), (512, 576, 12288), (256, 1600, 49152)])      # ... c3, c2 and c5 per GPU at full size
 def test_bmu_cosine_x3_rerank(ops, B, K, L):
     """Reduced-precision contraction + exact re-rank: norms, distances (1e-5 abs vs fp64: the three-product error is
     <= 4.6e-5 in the worst case, ~1e-7 observed), bmu == first argmin of the returned distances, and bmu equal to the
@@ -386,6 +386,33 @@ def test_bmu_cosine_x3_forced_rerank(ops):
     assert torch.equal(bmu.cpu()[clear], ref[clear]), (bmu.cpu(), ref, gap)
     assert torch.equal(bmu.cpu(), dist.cpu().argmin(1))
     assert float((dist.cpu().double() - d64).abs().max()) < 1e-5
+
+
+def test_bmu_cosine_x3_more_candidates_than_one_chunk(ops):
+    """More than 256 prototypes inside the re-rank window (collapsed prototypes late in training, or a dead input): the
+    candidates are re-ranked 256 at a time, none is dropped -- the BMU is still the fp64 argmin, exact ties go to the lowest
+    index, and a zero input row (all distances equal 1) yields index 0."""
+    B, K, L = 6, 700, 512
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(B, L, generator=g)
+    base = torch.randn(L, generator=g)
+    W = base.unsqueeze(0) + 1e-4 * torch.randn(K, L, generator=g)        # 700 prototypes within ~1e-8 of each other in cosine distance
+    W[650] = W[20]                                                        # an exact tie between two far-apart slots
+    x[3] = 0.0                                                            # dead input: every distance is exactly 1
+    d64 = 1 - F.normalize(x.double(), dim=1) @ F.normalize(W.double(), dim=1).T
+    inx, inw = torch.empty(B, device=DEV), torch.empty(K, device=DEV)
+    dist, bmu = torch.empty(B, K, device=DEV), torch.empty(B, dtype=torch.int64, device=DEV)
+    cnt = torch.zeros(1, dtype=torch.int32, device=DEV)
+    ops.bmu_cosine_x3_fwd(dev(x), dev(W), dist, bmu, inx, inw, cnt)
+    assert int(cnt) == B
+    assert torch.equal(bmu.cpu(), dist.cpu().argmin(1))
+    assert int(bmu[3]) == 0
+    live = torch.tensor([0, 1, 2, 4, 5])
+    chosen = d64[live].gather(1, bmu.cpu()[live].view(-1, 1)).squeeze(1)
+    assert float((chosen - d64[live].min(1).values).abs().max()) < 1.5e-7              # the exact distances are rounded to fp32 (ulp 6e-8 at 1.0) before they are compared
+    assert float((dist.cpu().double() - d64).abs().max()) < 1e-5
+    for i in live.tolist():                                                              # the tied pair never resolves to the higher slot
+        assert int(bmu[i]) != 650
 
 
 def test_bmu_exact_ties_pick_lowest_index(ops):

@@ -16,12 +16,15 @@
 //     whole row); the exact distances replace the approximate ones in dist and the BMU is their first minimum.
 //     Since BMU_WINDOW > 2 x the contraction's error bound, the true minimum is always among the candidates and
 //     every prototype outside keeps a value above the winner's: bmu == argmin(dist) holds exactly, and bmu is
-//     the argmin of distances that are exact to fp64 rounding wherever it matters.
+//     the argmin of distances that are exact to fp64 rounding wherever it matters.  The candidates get their slots
+//     from a block-wide prefix sum (deterministic, column order) and are re-ranked 256 at a time, however many there
+//     are (all K of them for a dead input or collapsed prototypes: exact ties then resolve to the lowest index).
 #include "gemm_x6.h"
 
 namespace vsom {
 
-constexpr float BMU_WINDOW = 1.0e-4f;      // > 2 * 3 * 2^-16 (split error, worst case) + fp32 accumulation slack
+constexpr float BMU_WINDOW = 2.0e-4f;      // 2 x (3 * 2^-16 = 4.6e-5, the split's worst case) = 9.2e-5, + as much again for the fp32
+                                           // accumulation over L <= 49152 terms and the slab sums
 
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
 
@@ -245,7 +248,7 @@ __global__ __launch_bounds__(256) void bmu_x3_finalize_kernel(const float* __res
     __shared__ float sb[4];
     __shared__ int si[4];
     __shared__ int cand[256];
-    __shared__ int ncand;
+    __shared__ int wtot[4];
     __shared__ double sd[4];
     const int i = blockIdx.x, t = threadIdx.x;
     const float rx = inv_nx[i];
@@ -303,53 +306,71 @@ __global__ __launch_bounds__(256) void bmu_x3_finalize_kernel(const float* __res
         if (ob < best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
     }
     if ((t & 63) == 0) { sb[t >> 6] = best; si[t >> 6] = bidx; }
-    if (t == 0) ncand = 0;
     __syncthreads();
     best = sb[0]; bidx = si[0];
 #pragma unroll
     for (int w = 1; w < 4; ++w)
         if (sb[w] < best || (sb[w] == best && si[w] < bidx)) { best = sb[w]; bidx = si[w]; }
-    // candidates: everything within the window of the approximate minimum (NaN never qualifies)
+    // candidates: everything within the window of the approximate minimum (NaN never qualifies).  Slot of a candidate =
+    // exclusive prefix sum of the per-thread counts (wave scan + the waves before it): deterministic.
     const float lim = best + BMU_WINDOW;
+    int mine = 0;
 #pragma unroll
-    for (int u = 0; u < BMU_KPT; ++u) {
-        const int k = kcol(u);
-        if (k < K && d[u] <= lim) {
-            const int slot = atomicAdd(&ncand, 1);
-            if (slot < 256) cand[slot] = k;
-        }
+    for (int u = 0; u < BMU_KPT; ++u) mine += (kcol(u) < K && d[u] <= lim) ? 1 : 0;
+    int incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o, 64);
+        if ((t & 63) >= o) incl += v;
     }
+    if ((t & 63) == 63) wtot[t >> 6] = incl;
     __syncthreads();
-    const int nc = ncand <= 256 ? ncand : 1;       // > 256 near-ties (degenerate input, e.g. identical prototypes): keep the approximate first minimum
+    int base = incl - mine;
+    for (int w = 0; w < (t >> 6); ++w) base += wtot[w];
+    const int nc = wtot[0] + wtot[1] + wtot[2] + wtot[3];
     if (nc > 1) {
-        // exact dots: fp32 products accumulated in fp64; this thread's share of x_i stays in registers
+        // exact dots: fp32 products accumulated in fp64; candidates 256 at a time
         const f32x4* xr = reinterpret_cast<const f32x4*>(X + (long)i * ldx);
         const int n4 = L >> 2;
         float ebest = INFINITY;
         int eidx = 0x7fffffff;
-        for (int c = 0; c < nc; ++c) {
-            const int k = cand[c];
-            const f32x4* wr = reinterpret_cast<const f32x4*>(W + (long)k * L);
-            double s0 = 0.0, s1 = 0.0;
-            int j = t;
-            for (; j + 256 < n4; j += 512) {
-                const f32x4 xa = xr[j], wa = wr[j], xb = xr[j + 256], wb = wr[j + 256];
-                s0 += (double)xa[0] * wa[0] + (double)xa[1] * wa[1] + (double)xa[2] * wa[2] + (double)xa[3] * wa[3];
-                s1 += (double)xb[0] * wb[0] + (double)xb[1] * wb[1] + (double)xb[2] * wb[2] + (double)xb[3] * wb[3];
+        for (int c0 = 0; c0 < nc; c0 += 256) {
+            __syncthreads();                       // cand free again
+            int slot = base;
+#pragma unroll
+            for (int u = 0; u < BMU_KPT; ++u) {
+                const int k = kcol(u);
+                if (k < K && d[u] <= lim) {
+                    if (slot >= c0 && slot < c0 + 256) cand[slot - c0] = k;
+                    ++slot;
+                }
             }
-            for (; j < n4; j += 256) {
-                const f32x4 xa = xr[j], wa = wr[j];
-                s0 += (double)xa[0] * wa[0] + (double)xa[1] * wa[1] + (double)xa[2] * wa[2] + (double)xa[3] * wa[3];
-            }
-            for (int e = (n4 << 2) + t; e < L; e += 256) s0 += (double)X[(long)i * ldx + e] * W[(long)k * L + e];
-            const double ws = wave_sum_f64(s0 + s1);
-            __syncthreads();                       // sd free again
-            if ((t & 63) == 0) sd[t >> 6] = ws;
             __syncthreads();
-            const double dotx = (sd[0] + sd[1]) + (sd[2] + sd[3]);
-            const float de = (float)(1.0 - dotx * (double)rx * (double)inv_nw[k]);
-            if (t == 0 && dist) dist[(long)i * K + k] = de;
-            if (de < ebest || (de == ebest && k < eidx)) { ebest = de; eidx = k; }
+            const int ncc = nc - c0 < 256 ? nc - c0 : 256;
+            for (int c = 0; c < ncc; ++c) {
+                const int k = cand[c];
+                const f32x4* wr = reinterpret_cast<const f32x4*>(W + (long)k * L);
+                double s0 = 0.0, s1 = 0.0;
+                int j = t;
+                for (; j + 256 < n4; j += 512) {
+                    const f32x4 xa = xr[j], wa = wr[j], xb = xr[j + 256], wb = wr[j + 256];
+                    s0 += (double)xa[0] * wa[0] + (double)xa[1] * wa[1] + (double)xa[2] * wa[2] + (double)xa[3] * wa[3];
+                    s1 += (double)xb[0] * wb[0] + (double)xb[1] * wb[1] + (double)xb[2] * wb[2] + (double)xb[3] * wb[3];
+                }
+                for (; j < n4; j += 256) {
+                    const f32x4 xa = xr[j], wa = wr[j];
+                    s0 += (double)xa[0] * wa[0] + (double)xa[1] * wa[1] + (double)xa[2] * wa[2] + (double)xa[3] * wa[3];
+                }
+                for (int e = (n4 << 2) + t; e < L; e += 256) s0 += (double)X[(long)i * ldx + e] * W[(long)k * L + e];
+                const double ws = wave_sum_f64(s0 + s1);
+                __syncthreads();                       // sd free again
+                if ((t & 63) == 0) sd[t >> 6] = ws;
+                __syncthreads();
+                const double dotx = (sd[0] + sd[1]) + (sd[2] + sd[3]);
+                const float de = (float)(1.0 - dotx * (double)rx * (double)inv_nw[k]);
+                if (t == 0 && dist) dist[(long)i * K + k] = de;
+                if (de < ebest || (de == ebest && k < eidx)) { ebest = de; eidx = k; }
+            }
         }
         bidx = eidx;
         if (t == 0 && rerank_count) atomicAdd(rerank_count, 1);
