@@ -528,6 +528,9 @@ static void rp_stamp_report(unsigned long long* dev, int nwaves, hipStream_t st)
     std::sort(starts.begin(), starts.end()); std::sort(ends.begin(), ends.end());
     fprintf(stderr, "[rp stamps] waves %d  kernel span %.1f us | per wave (median, cycles): prologue %llu  loop %llu (waits %llu, mfma-phase %llu) tiles %llu\n",
             nwaves, (r1 - r0) / 100.0, med(1), med(2), med(3), med(4), med(7));
+    { std::vector<double> ghz; for (int w = 0; w < nwaves; ++w) ghz.push_back((double)(h[w * 8 + 1] + h[w * 8 + 2]) / ((h[w * 8 + 5] - h[w * 8]) * 10.0));
+      std::sort(ghz.begin(), ghz.end());
+      fprintf(stderr, "[rp stamps] in-kernel clock (s_memtime ticks per ns of s_memrealtime), GHz: p10 %.2f p50 %.2f p90 %.2f\n", ghz[nwaves / 10], ghz[nwaves / 2], ghz[nwaves * 9 / 10]); }
     fprintf(stderr, "[rp stamps] wave start us: p10 %.1f p50 %.1f p90 %.1f max %.1f | end us: p10 %.1f p50 %.1f p90 %.1f\n", starts[nwaves / 10], starts[nwaves / 2],
             starts[nwaves * 9 / 10], starts.back(), ends[nwaves / 10], ends[nwaves / 2], ends[nwaves * 9 / 10]);
 }

@@ -4,7 +4,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from vit_som_amd import ops
-T, E, H4 = 512 * 65, 192, 768
+T, E, H4 = int(os.environ.get("RP_T", 512 * 65)), 192, 768
 if len(sys.argv) > 1 and sys.argv[1].startswith("T="):
     T = int(sys.argv.pop(1)[2:])
 dev = "cuda"

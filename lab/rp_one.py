@@ -5,7 +5,7 @@ import torch
 from vit_som_amd import ops
 which = sys.argv[1] if len(sys.argv) > 1 else "qkv"
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 20
-T, E, H4 = 512 * 65, 192, 768
+T, E, H4 = int(os.environ.get("RP_T", 512 * 65)), 192, 768
 dev = "cuda"
 torch.manual_seed(0)
 shapes = {"qkv": (E, 3 * E, 0), "proj": (E, E, 0), "fc1": (E, H4, 0), "fc2": (H4, E, 0), "dxfc2": (E, H4, 1), "dxqkv": (3 * E, E, 1)}

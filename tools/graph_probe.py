@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 from vit_som_amd import ViTSOM
 
-B = 512
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 torch.manual_seed(0)
 m = ViTSOM(bench.c3_config(B), device="cuda")
 m.set_schedule(50000, 48500); m._it = 1000
