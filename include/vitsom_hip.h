@@ -257,6 +257,34 @@ int vsom_comm_allreduce_sum(float* buf, long n, vsom_stream_t stream);
 int vsom_comm_info(int* world_size, int* rank);
 int vsom_comm_destroy(void);
 
+/* ------------------------------------------------------------------ launch tape (the step as ONE host call per segment) */
+/* The reference drives its step from Python through ATen, one host round trip per op (vit_som.py:80-105 under Lightning's fit
+ * loop); so does the host mirror, ~420 launches and ~4 ms of host time per step -- more than the GPU needs below ~256 images
+ * per GPU (BASELINE c4 at 128 per GPU, c3 read as 512 global).  A tape records the launches of one step WHILE THEY RUN and
+ * re-issues them from C:
+ *   vsom_tape_begin      start recording on the calling thread; returns the tape id (> 0).  Every launch any vsom_* entry
+ *                        makes on this thread from now on is executed AND kept (kernel, grid, LDS, stream, by-value arguments),
+ *                        as are vsom_event_record / vsom_stream_wait_event and vsom_comm_allreduce_sum
+ *   vsom_tape_cut        close the current segment, open the next; returns the index of the closed one
+ *   vsom_tape_pause      1: execute but do not keep what follows (calls whose arguments change per step), 0: resume
+ *   vsom_tape_end        stop recording; returns the number of segments
+ *   vsom_tape_replay     re-issue one segment's operations in order (no per-launch host work beyond hipLaunchKernel)
+ *   vsom_tape_segment_ops / vsom_tape_recording (0 no, 1 recording, 2 paused) / vsom_tape_destroy
+ * Pointers are frozen into the tape: the caller replays only while every buffer the recorded step touched is alive and in
+ * place (the host mirror stages each batch into fixed input buffers and ties the tape to its activation buffers).
+ *   vsom_event_record / vsom_stream_wait_event: library-owned events (ids 0..511, created on first use) for the edges
+ *   between the step's HIP streams, so that they are part of a tape. */
+int vsom_tape_begin(void);
+int vsom_tape_cut(void);
+int vsom_tape_pause(int paused);
+int vsom_tape_end(void);
+int vsom_tape_recording(void);
+int vsom_tape_segment_ops(int tape, int segment);
+int vsom_tape_replay(int tape, int segment);
+int vsom_tape_destroy(int tape);
+int vsom_event_record(int ev, vsom_stream_t stream);
+int vsom_stream_wait_event(vsom_stream_t stream, int ev);
+
 /* ------------------------------------------------------------------ evaluation (tools/evaluation.py) */
 /* table[a[i] * nb + b[i]] += 1 for i < n  (uint64 counts, accumulates: zero it before the first
  * batch) -- the contingency matrix of calculate_purity (evaluation.py:142-145) and of the

@@ -161,6 +161,8 @@ def test_vsom_comm_rccl_one_rank_bucketed_exchange_keeps_the_trajectory():
     import vit_som_amd
     from oracle.gen_golden import make_config
     from vit_som_amd import ops
+    from vit_som_amd.tuning import hooks
+    hooks.set(launch_tape=False)            # this test counts the exchange calls the HOST issues (the taped form: next test)
     cfg = make_config(3, 32, 4, 192, 6, 3, 96, 2, (12, 12), 0, 64)
     g = torch.Generator().manual_seed(1)
     x = torch.rand(64, 3, 32, 32, generator=g).cuda()
@@ -198,15 +200,27 @@ def test_vsom_comm_rccl_one_rank_bucketed_exchange_keeps_the_trajectory():
                 ops.comm_allreduce_sum = orig
         return [float(v) for v in losses], m.arena.params.clone(), calls, m.arena.numel
 
-    l0, p0, _, _ = run(False)
     try:
-        l1, p1, calls, numel = run(True)
+        l0, p0, _, _ = run(False)
+        try:
+            l1, p1, calls, numel = run(True)
+        finally:
+            ops.comm_destroy()
+        assert ops.comm_info() == (0, -1)
+        per_step = len(calls) // 6
+        assert per_step >= 4 and sum(calls) == 6 * numel, (per_step, sum(calls), numel)      # every float reduced exactly once per step
+        assert l0 == l1 and torch.equal(p0, p1)
+        # the same exchange recorded on a launch tape: the collectives of the backward are re-issued from C with the step's
+        # other launches, the remainder by allreduce_gradients(); same trajectory
+        hooks.set(launch_tape=True)
+        try:
+            l2, p2, calls2, _ = run(True)
+        finally:
+            ops.comm_destroy()
+        assert l0 == l2 and torch.equal(p0, p2)
+        assert len(calls2) < len(calls)          # steps 4-6 issued only the remainder piece from the host
     finally:
-        ops.comm_destroy()
-    assert ops.comm_info() == (0, -1)
-    per_step = len(calls) // 6
-    assert per_step >= 4 and sum(calls) == 6 * numel, (per_step, sum(calls), numel)      # every float reduced exactly once per step
-    assert l0 == l1 and torch.equal(p0, p1)
+        hooks.reset()
 
 
 def _train_worker(rank, world, port, out, mode):

@@ -662,3 +662,52 @@ def test_loss_parts_are_plain_tensors_with_a_lifetime():
         m.train_step_fused(x1, y1)
         m.validation_step((x1, y1), 0)
     assert {k: float(first[k]) for k in ("total", "main", "som")} == v0 and float(l0) == v0["total"]
+
+
+@pytest.mark.parametrize("mode,B", [("cluster", 64), ("cls", 24)])
+def test_launch_tape_replays_the_step_bit_for_bit(mode, B):
+    """The launch tape (vsom_tape_*): after two host-driven steps the third is recorded while it runs and every later
+    step re-issues those launches from C.  8 steps through train_step_fused AND through training_step().backward() (with a
+    loss seed other than 1: segment 2) must leave bit-identical parameters, losses and logged terms with the tape on and off;
+    a validation step in between (host-driven, same buffers) must not disturb it."""
+    import vit_som_amd
+    from oracle.gen_golden import make_config
+    from vit_som_amd import ops
+    from vit_som_amd.tuning import hooks
+    cfg = make_config(3, 32, 4, 192, 3, 3, 96, 2, (8, 8), 10 if mode == "cls" else 0, B, gamma=0.02, Tmax=4.0, Tmin=0.1)
+    g = torch.Generator().manual_seed(3)
+    xs = [torch.randn(B, 3, 32, 32, generator=g).to(DEV) for _ in range(8)]
+    ys = [torch.randint(0, 10, (B,), generator=g).to(DEV) for _ in range(8)]
+
+    def run(tape_on):
+        hooks.set(launch_tape=tape_on)
+        try:
+            torch.manual_seed(0)
+            m = vit_som_amd.ViTSOM(copy.deepcopy(cfg), device=DEV)
+            m.set_schedule(4000, 400)
+            m._it = 40
+            (opt,), _ = m.configure_optimizers()
+            out = []
+            for i in range(8):
+                if i % 3 == 2:                                      # the autograd bridge, seed 0.5
+                    loss = m.training_step((xs[i], ys[i]), i)
+                    (0.5 * loss).backward()
+                else:
+                    loss = m.train_step_fused(xs[i], ys[i])
+                out.append((float(loss), float(m._last["main"]), float(m._last["som"])))
+                opt.step()
+                if i == 4:
+                    m.validation_step((xs[0], ys[0]), 0)
+            torch.cuda.synchronize()
+            a = m.vit._acts[B]
+            return out, m.arena.params.clone(), m.arena.grads.clone(), a.__dict__.get("tape"), int(m.iteration)
+        finally:
+            hooks.reset()
+
+    o0, p0, g0, t0, it0 = run(False)
+    o1, p1, g1, t1, it1 = run(True)
+    assert t0 is None and t1 is not None and t1.id > 0
+    nops = [ops.tape_segment_ops(t1.id, k) for k in range(4)]
+    assert nops[0] > 20 and nops[1] >= 1 and nops[2] == 4 and nops[3] > 60, nops
+    assert o0 == o1 and it0 == it1 == 8            # the device-side iteration buffer advanced once per training step, replayed or not
+    assert torch.equal(g0, g1) and torch.equal(p0, p1)

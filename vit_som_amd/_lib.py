@@ -47,6 +47,16 @@ SIGNATURES = {
     "vsom_attention_bwd": (C.c_int, [c_fp] * 6 + [C.c_int] * 4 + [c_stream]),
     "vsom_set_attention_fused": (C.c_int, [C.c_int]),
     "vsom_attention_probs": (C.c_int, [c_fp, c_fp, c_fp, C.c_int, C.c_int, C.c_int, C.c_int, c_stream]),
+    "vsom_tape_begin": (C.c_int, []),
+    "vsom_tape_cut": (C.c_int, []),
+    "vsom_tape_pause": (C.c_int, [C.c_int]),
+    "vsom_tape_end": (C.c_int, []),
+    "vsom_tape_recording": (C.c_int, []),
+    "vsom_tape_segment_ops": (C.c_int, [C.c_int, C.c_int]),
+    "vsom_tape_replay": (C.c_int, [C.c_int, C.c_int]),
+    "vsom_tape_destroy": (C.c_int, [C.c_int]),
+    "vsom_event_record": (C.c_int, [C.c_int, c_stream]),
+    "vsom_stream_wait_event": (C.c_int, [c_stream, C.c_int]),
     "vsom_comm_unique_id": (C.c_int, [C.c_void_p]),
     "vsom_comm_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int]),
     "vsom_comm_allreduce_sum": (C.c_int, [c_fp, C.c_long, c_stream]),
@@ -163,3 +173,41 @@ def stream():
     if _raw_stream is not None and _cur_device is not None:
         return _raw_stream(_cur_device())
     return torch.cuda.current_stream().cuda_stream
+
+
+class Event:
+    """A library-owned HIP event (vsom_event_record / vsom_stream_wait_event): an ordering edge between two of the step's
+    streams that a launch tape can hold (torch.cuda.Event records would be invisible to it).  Ids come from a process-wide
+    pool of 512; `Event.pooled()` hands out round-robin events for record-then-wait edges that are consumed at once."""
+    _next_id = 0
+    _pool, _pool_pos = [], 0
+    POOL = 192
+
+    def __init__(self):
+        if Event._next_id >= 512:
+            raise RuntimeError("vit_som_amd: out of library events (512)")
+        self.id = Event._next_id
+        Event._next_id += 1
+
+    @classmethod
+    def pooled(cls):
+        if len(cls._pool) < cls.POOL:
+            cls._pool.append(cls())
+        cls._pool_pos = (cls._pool_pos + 1) % cls.POOL
+        return cls._pool[cls._pool_pos % len(cls._pool)]
+
+    def record(self, torch_stream=None):
+        """Record on `torch_stream` (default: the stream launches currently go to)."""
+        check(lib.vsom_event_record(self.id, torch_stream.cuda_stream if torch_stream is not None else stream()), "vsom_event_record")
+        return self
+
+    def wait(self, torch_stream=None):
+        """Make `torch_stream` (default: the launch stream) wait for the last record of this event."""
+        check(lib.vsom_stream_wait_event(torch_stream.cuda_stream if torch_stream is not None else stream(), self.id),
+              "vsom_stream_wait_event")
+
+
+def stream_wait_stream(waiter, other):
+    """`waiter` (a torch stream or None = the launch stream) waits for everything enqueued on `other` so far."""
+    ev = Event.pooled().record(other)
+    ev.wait(waiter)

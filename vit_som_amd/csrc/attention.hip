@@ -1164,7 +1164,7 @@ static size_t attn_fused_lds_bytes(int N, int hdp) {
 template <int HDP, bool EXTRA>
 static int launch_fwd_t(const float* qkv, float* out, float* lse, int B, int N, int H, int hd, hipStream_t st) {
     const size_t lds = attn_lds_bytes(N, HDP, false, HDP + 2);
-    hipLaunchKernelGGL((attn_fwd_kernel<HDP, EXTRA>), dim3(B * H), dim3(64 * attn_waves(N)), lds, st, qkv, out, lse, N, H, hd,
+    VSOM_LAUNCH((attn_fwd_kernel<HDP, EXTRA>), dim3(B * H), dim3(64 * attn_waves(N)), lds, st, qkv, out, lse, N, H, hd,
                        1.0f / sqrtf((float)hd));
     VSOM_LAUNCH_CHECK("attn_fwd_kernel");
 }
@@ -1180,21 +1180,21 @@ static int launch_bwd_t(const float* qkv, const float* out, const float* dout, c
         const int nt = attn_tiles(N), nrows = use_extra(N) ? N : nt * 16;
         const size_t shared_lds = fused_lds + 2 * HDP * sizeof(float);
         if (mode == 1 && nt <= 4 && attn_waves(N) == nt && 16 * nt * (16 * nt + 4) <= nrows * (HDP + 4) && shared_lds <= 80 * 1024) {
-            hipLaunchKernelGGL((attn_bwd_shared_kernel<HDP, EXTRA>), dim3(B * H), block, shared_lds, st, qkv, out, dout, lse, dqkv,
+            VSOM_LAUNCH((attn_bwd_shared_kernel<HDP, EXTRA>), dim3(B * H), block, shared_lds, st, qkv, out, dout, lse, dqkv,
                                delta, N, H, hd, scale);
             VSOM_LAUNCH_CHECK("attn_bwd_shared_kernel");
         }
     }
     if (ACfg<HDP>::VEC && fused_lds <= 80 * 1024 && mode) {
-        hipLaunchKernelGGL((attn_bwd_fused_kernel<HDP, EXTRA>), dim3(B * H), block, fused_lds, st, qkv, out, dout, lse, dqkv,
+        VSOM_LAUNCH((attn_bwd_fused_kernel<HDP, EXTRA>), dim3(B * H), block, fused_lds, st, qkv, out, dout, lse, dqkv,
                            delta, N, H, hd, scale);
         VSOM_LAUNCH_CHECK("attn_bwd_fused_kernel");
     }
-    hipLaunchKernelGGL((attn_bwd_dq_kernel<HDP, EXTRA>), dim3(B * H), block, attn_lds_bytes(N, HDP, false, HDP), st, qkv, out,
+    VSOM_LAUNCH((attn_bwd_dq_kernel<HDP, EXTRA>), dim3(B * H), block, attn_lds_bytes(N, HDP, false, HDP), st, qkv, out,
                        dout, lse, dqkv, delta, N, H, hd, scale);
     int rc = hip_status(hipGetLastError(), "attn_bwd_dq_kernel");
     if (rc) return rc;
-    hipLaunchKernelGGL((attn_bwd_dkv_kernel<HDP, EXTRA>), dim3(B * H), block, attn_lds_bytes(N, HDP, true, 2 * HDP), st, qkv,
+    VSOM_LAUNCH((attn_bwd_dkv_kernel<HDP, EXTRA>), dim3(B * H), block, attn_lds_bytes(N, HDP, true, 2 * HDP), st, qkv,
                        dout, lse, delta, dqkv, N, H, hd, scale);
     VSOM_LAUNCH_CHECK("attn_bwd_dkv_kernel");
 }
@@ -1286,7 +1286,7 @@ int vsom_attention_probs(const float* qkv, const float* lse, float* probs, int B
     VSOM_REQUIRE(qkv && lse && probs, VSOM_EINVAL, "attention_probs: null pointer");
     VSOM_REQUIRE(B > 0 && N > 0 && H > 0 && hd > 0, VSOM_EINVAL, "attention_probs: bad shape B=%d N=%d H=%d hd=%d", B, N, H, hd);
     const int by = cdiv((long)N * N, 256) < 64 ? cdiv((long)N * N, 256) : 64;
-    hipLaunchKernelGGL(attn_probs_kernel, dim3(B * H, by), dim3(256), 0, stream, qkv, lse, probs, N, H, hd, 1.0f / sqrtf((float)hd));
+    VSOM_LAUNCH(attn_probs_kernel, dim3(B * H, by), dim3(256), 0, stream, qkv, lse, probs, N, H, hd, 1.0f / sqrtf((float)hd));
     VSOM_LAUNCH_CHECK("attn_probs_kernel");
 }
 

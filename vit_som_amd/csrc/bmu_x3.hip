@@ -438,8 +438,8 @@ int vsom_bmu_cosine_x3_dots(const float* X, long ldx, const float* W, int B, int
     g.X = X; g.ldx = ldx; g.W = W; g.B = B; g.K = K; g.L = L;
     g.ktiles_per_split = cdiv(cdiv(L, 32), splits);
     g.x_bytes = (unsigned)xb; g.w_bytes = (unsigned)wb;
-    if (bmu_x3_big(B)) hipLaunchKernelGGL((bmu_x3_kernel<2, 3, 4, 2>), dim3(bmu_x3_tiles(B, K) * splits), dim3(512), 0, stream, g);
-    else hipLaunchKernelGGL((bmu_x3_kernel<2, 2, 2, 2>), dim3(bmu_x3_tiles(B, K) * splits), dim3(256), 0, stream, g);
+    if (bmu_x3_big(B)) VSOM_LAUNCH((bmu_x3_kernel<2, 3, 4, 2>), dim3(bmu_x3_tiles(B, K) * splits), dim3(512), 0, stream, g);
+    else VSOM_LAUNCH((bmu_x3_kernel<2, 2, 2, 2>), dim3(bmu_x3_tiles(B, K) * splits), dim3(256), 0, stream, g);
     VSOM_LAUNCH_CHECK("bmu_x3_kernel");
 }
 
@@ -454,15 +454,15 @@ int vsom_bmu_cosine_x3_finalize(const float* X, long ldx, const float* W, const 
     BmuP g = {};
     int splits; int* counter;
     x3_layout(B, K, L, const_cast<void*>(ws), g, splits, &counter);
-    hipLaunchKernelGGL(bmu_norms_kernel, dim3(cdiv(B + K, 256)), dim3(256), 0, stream, g.xsq, g.wsq, splits, B, K, inv_nx, inv_nw);
+    VSOM_LAUNCH(bmu_norms_kernel, dim3(cdiv(B + K, 256)), dim3(256), 0, stream, g.xsq, g.wsq, splits, B, K, inv_nx, inv_nw);
     int rc = hip_status(hipGetLastError(), "bmu_norms_kernel");
     if (rc) return rc;
     const bool v4 = K % 4 == 0 && aligned16(g.slab) && g.slab_stride % 4 == 0;
     if (v4)
-        hipLaunchKernelGGL(bmu_x3_finalize_kernel<true>, dim3(B), dim3(256), 0, stream, g.slab, g.slab_stride, splits, X, ldx, W, inv_nx,
+        VSOM_LAUNCH(bmu_x3_finalize_kernel<true>, dim3(B), dim3(256), 0, stream, g.slab, g.slab_stride, splits, X, ldx, W, inv_nx,
                            inv_nw, dist, bmu, K, L, reranked);
     else
-    hipLaunchKernelGGL(bmu_x3_finalize_kernel<false>, dim3(B), dim3(256), 0, stream, g.slab, g.slab_stride, splits, X, ldx, W, inv_nx,
+    VSOM_LAUNCH(bmu_x3_finalize_kernel<false>, dim3(B), dim3(256), 0, stream, g.slab, g.slab_stride, splits, X, ldx, W, inv_nx,
                        inv_nw, dist, bmu, K, L, reranked);
     VSOM_LAUNCH_CHECK("bmu_x3_finalize_kernel");
 }

@@ -102,7 +102,10 @@ int vsom_comm_allreduce_sum(float* buf, long n, vsom_stream_t stream) {
     VSOM_REQUIRE(buf && n >= 0, VSOM_EINVAL, "comm_allreduce_sum: bad arguments");
     VSOM_REQUIRE(g_comm != nullptr, VSOM_EINVAL, "comm_allreduce_sum: no communicator (vsom_comm_init first)");
     if (n == 0) return VSOM_OK;
-    return rccl_status(g_rccl.AllReduce(buf, buf, (size_t)n, ncclFloat32, ncclSum, g_comm, stream), "ncclAllReduce");
+    const int rc = rccl_status(g_rccl.AllReduce(buf, buf, (size_t)n, ncclFloat32, ncclSum, g_comm, stream), "ncclAllReduce");
+    if (rc == VSOM_OK && g_tape_rec)                  // a recorded step re-issues its collectives too (same order on every rank)
+        tape_push([=]() { (void)g_rccl.AllReduce(buf, buf, (size_t)n, ncclFloat32, ncclSum, g_comm, stream); });
+    return rc;
 }
 
 int vsom_comm_info(int* world_size, int* rank) {

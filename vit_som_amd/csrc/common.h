@@ -5,6 +5,9 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <functional>
+#include <utility>
+
 #include "../../include/vitsom_hip.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -30,6 +33,23 @@ inline int hip_status(hipError_t e, const char* what) {
     } while (0)
 
 #define VSOM_LAUNCH_CHECK(name) return ::vsom::hip_status(hipGetLastError(), name)
+
+// ---- launch tape (tape.hip): every kernel launch of the library goes through VSOM_LAUNCH.  Normally that IS
+// hipLaunchKernelGGL; while the calling thread records a tape (vsom_tape_begin) the launch is also kept -- kernel, grid, block,
+// LDS size, stream and the by-value arguments, all inside one closure -- so that vsom_tape_replay can re-issue a whole
+// training step's launches from C in one call (the host mirror's Python + ctypes path costs ~9 us per launch, 4 ms per
+// step: host-bound below ~256 images per GPU).
+struct TapeRec;
+extern thread_local TapeRec* g_tape_rec;                    // non-null while this thread records (and is not paused)
+void tape_push(std::function<void()>&& op);
+
+template <class F>
+inline void launch_or_record(F&& f) {
+    f();
+    if (g_tape_rec) tape_push(std::function<void()>(std::forward<F>(f)));
+}
+#define VSOM_LAUNCH(kernel, grid, block, lds, stream, ...)                                       \
+    ::vsom::launch_or_record([=]() { hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__); })
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

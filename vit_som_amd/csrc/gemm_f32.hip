@@ -53,21 +53,21 @@ static int launch_t(GemmP& g, int splits, hipStream_t stream) {
     g.n_major = bb > ab;        // share the larger operand's panel between neighbouring workgroups
     if constexpr (!A_KC && !B_KC && (EPI == EPI_SLAB || EPI == EPI_ROWAXPY)) {
         if (fast && gemm_mode() == VSOM_GEMM_SPLIT_BF16) {
-            if (BM == 64) hipLaunchKernelGGL((gemm_x6_kernel<false, false, 1, 1, 2, 2, EPI>), grid, block, 0, stream, g);
-            else hipLaunchKernelGGL((gemm_x6_kernel<false, false, 1, 2, 4, 1, EPI>), grid, block, 0, stream, g);
+            if (BM == 64) VSOM_LAUNCH((gemm_x6_kernel<false, false, 1, 1, 2, 2, EPI>), grid, block, 0, stream, g);
+            else VSOM_LAUNCH((gemm_x6_kernel<false, false, 1, 2, 4, 1, EPI>), grid, block, 0, stream, g);
             VSOM_LAUNCH_CHECK("gemm_x6_kernel");
         }
     }
     if constexpr (!A_KC && !B_KC) {
         if (BM == 64) {
-            if (fast) hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, 1, 1, 2, 2, EPI, true>), grid, block, 0, stream, g);
-            else hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, 1, 1, 2, 2, EPI, false>), grid, block, 0, stream, g);
+            if (fast) VSOM_LAUNCH((gemm_f32_kernel<A_KC, B_KC, 1, 1, 2, 2, EPI, true>), grid, block, 0, stream, g);
+            else VSOM_LAUNCH((gemm_f32_kernel<A_KC, B_KC, 1, 1, 2, 2, EPI, false>), grid, block, 0, stream, g);
             VSOM_LAUNCH_CHECK("gemm_f32_kernel");
         }
     }
     if constexpr (A_KC && !B_KC && EPI == EPI_ROWAXPY) {
         if (fast && gemm_mode() == VSOM_GEMM_SPLIT_BF16) {
-            hipLaunchKernelGGL((gemm_x6_kernel<true, false, 1, 2, 4, 1, EPI>), grid, block, 0, stream, g);
+            VSOM_LAUNCH((gemm_x6_kernel<true, false, 1, 2, 4, 1, EPI>), grid, block, 0, stream, g);
             VSOM_LAUNCH_CHECK("gemm_x6_kernel");
         }
     }
@@ -80,17 +80,17 @@ static int launch_t(GemmP& g, int splits, hipStream_t stream) {
             // 11.07-11.14 -> 10.77-10.83 ms; restricting 64 x 64 to launches of < 512 or < 256 large tiles: 10.91 / 10.85.)
             if (g.M <= 64) {
                 dim3 grid64(cdiv(g.M, 64) * cdiv(g.N, 64) * splits, 1, 1);
-                hipLaunchKernelGGL((gemm_x6_kernel<true, true, 1, 1, 2, 2, EPI>), grid64, block, 0, stream, g);
+                VSOM_LAUNCH((gemm_x6_kernel<true, true, 1, 1, 2, 2, EPI>), grid64, block, 0, stream, g);
                 VSOM_LAUNCH_CHECK("gemm_x6_kernel");
             }
-            hipLaunchKernelGGL((gemm_x6_kernel<true, true, 1, 2, 4, 1, EPI>), grid, block, 0, stream, g);
+            VSOM_LAUNCH((gemm_x6_kernel<true, true, 1, 2, 4, 1, EPI>), grid, block, 0, stream, g);
             VSOM_LAUNCH_CHECK("gemm_x6_kernel");
         }
     }
     if (fast)
-        hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, 1, 2, 4, 1, EPI, true>), grid, block, 0, stream, g);
+        VSOM_LAUNCH((gemm_f32_kernel<A_KC, B_KC, 1, 2, 4, 1, EPI, true>), grid, block, 0, stream, g);
     else
-        hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, 1, 2, 4, 1, EPI, false>), grid, block, 0, stream, g);
+        VSOM_LAUNCH((gemm_f32_kernel<A_KC, B_KC, 1, 2, 4, 1, EPI, false>), grid, block, 0, stream, g);
     VSOM_LAUNCH_CHECK("gemm_f32_kernel");
 }
 
@@ -200,11 +200,11 @@ int reduce_slabs2_internal(const float* slabs, long stride, int nslabs, float* o
     const int vec = aligned16(slabs) && (stride % 4 == 0) && (off2 % 4 == 0);
     if (n1 + n2 <= 4096 && nslabs >= 32) {
         const int nb1 = cdiv(n1, 64), nb2 = n2 > 0 ? cdiv(n2, 64) : 0;
-        hipLaunchKernelGGL((reduce_slabs_kernel<16, 1>), dim3(nb1 + nb2), dim3(1024), 0, stream, slabs, stride, nslabs, out1,
+        VSOM_LAUNCH((reduce_slabs_kernel<16, 1>), dim3(nb1 + nb2), dim3(1024), 0, stream, slabs, stride, nslabs, out1,
                            n1, out2, off2, n2, nb1, vec);
     } else {
         const int nb1 = cdiv(n1, 256), nb2 = n2 > 0 ? cdiv(n2, 256) : 0;
-        hipLaunchKernelGGL((reduce_slabs_kernel<4, 4>), dim3(nb1 + nb2), dim3(256), 0, stream, slabs, stride, nslabs, out1, n1,
+        VSOM_LAUNCH((reduce_slabs_kernel<4, 4>), dim3(nb1 + nb2), dim3(256), 0, stream, slabs, stride, nslabs, out1, n1,
                            out2, off2, n2, nb1, vec);
     }
     VSOM_LAUNCH_CHECK("reduce_slabs_kernel");
@@ -302,9 +302,9 @@ int linear_bwd_weight_impl(const float* dY, long lddy, const float* X, long ldx,
         t.slab_bias = db ? slab + wlen : nullptr; t.slab_bias_stride = wlen + blen;
         t.a_bytes = (unsigned)ab; t.b_bytes = (unsigned)bb;
         if (plan.cfg == 1)
-            hipLaunchKernelGGL((gemm_x6_tn_kernel<3, 1, 2, 2>), dim3((N / 192) * (K / 64) * splits), dim3(256), 0, stream, t);
+            VSOM_LAUNCH((gemm_x6_tn_kernel<3, 1, 2, 2>), dim3((N / 192) * (K / 64) * splits), dim3(256), 0, stream, t);
         else
-            hipLaunchKernelGGL((gemm_x6_tn_kernel<3, 1, 1, 3>), dim3((N / 96) * (K / 96) * splits), dim3(192), 0, stream, t);
+            VSOM_LAUNCH((gemm_x6_tn_kernel<3, 1, 1, 3>), dim3((N / 96) * (K / 96) * splits), dim3(192), 0, stream, t);
         const int rc = hip_status(hipGetLastError(), "gemm_x6_tn_kernel");
         if (rc) return rc;
         return reduce_slabs2_internal(slab, wlen + blen, splits, dW, (long)N * K, db, wlen, db ? N : 0, stream);

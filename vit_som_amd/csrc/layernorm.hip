@@ -256,17 +256,17 @@ int vsom_layernorm_fwd(const float* X, const float* gamma, const float* beta, fl
     if (cols % 4 == 0 && cols <= 256 && aligned16(X) && aligned16(Y) && aligned16(gamma) && aligned16(beta)) {
         dim3 g16(cdiv(rows, 16));
         switch ((cols + 63) / 64) {
-            case 1: hipLaunchKernelGGL(layernorm_fwd_v4_kernel<1>, g16, block, 0, stream, X, gamma, beta, Y, mean, rstd, rows, cols, eps); break;
-            case 2: hipLaunchKernelGGL(layernorm_fwd_v4_kernel<2>, g16, block, 0, stream, X, gamma, beta, Y, mean, rstd, rows, cols, eps); break;
-            case 3: hipLaunchKernelGGL(layernorm_fwd_v4_kernel<3>, g16, block, 0, stream, X, gamma, beta, Y, mean, rstd, rows, cols, eps); break;
-            default: hipLaunchKernelGGL(layernorm_fwd_v4_kernel<4>, g16, block, 0, stream, X, gamma, beta, Y, mean, rstd, rows, cols, eps); break;
+            case 1: VSOM_LAUNCH(layernorm_fwd_v4_kernel<1>, g16, block, 0, stream, X, gamma, beta, Y, mean, rstd, rows, cols, eps); break;
+            case 2: VSOM_LAUNCH(layernorm_fwd_v4_kernel<2>, g16, block, 0, stream, X, gamma, beta, Y, mean, rstd, rows, cols, eps); break;
+            case 3: VSOM_LAUNCH(layernorm_fwd_v4_kernel<3>, g16, block, 0, stream, X, gamma, beta, Y, mean, rstd, rows, cols, eps); break;
+            default: VSOM_LAUNCH(layernorm_fwd_v4_kernel<4>, g16, block, 0, stream, X, gamma, beta, Y, mean, rstd, rows, cols, eps); break;
         }
         VSOM_LAUNCH_CHECK("layernorm_fwd_v4_kernel");
     }
     if (cols <= 256)
-        hipLaunchKernelGGL(layernorm_fwd_kernel<4>, grid, block, 0, stream, X, gamma, beta, Y, mean, rstd, rows, cols, eps);
+        VSOM_LAUNCH(layernorm_fwd_kernel<4>, grid, block, 0, stream, X, gamma, beta, Y, mean, rstd, rows, cols, eps);
     else
-        hipLaunchKernelGGL(layernorm_fwd_kernel<16>, grid, block, 0, stream, X, gamma, beta, Y, mean, rstd, rows, cols, eps);
+        VSOM_LAUNCH(layernorm_fwd_kernel<16>, grid, block, 0, stream, X, gamma, beta, Y, mean, rstd, rows, cols, eps);
     VSOM_LAUNCH_CHECK("layernorm_fwd_kernel");
 }
 
@@ -290,15 +290,15 @@ int vsom_layernorm_bwd(const float* dY, const float* X, const float* mean, const
                     (!resid || aligned16(resid));
     if (v4) {
         switch ((cols + 63) / 64) {
-            case 1: hipLaunchKernelGGL(layernorm_bwd_v4_kernel<1>, dim3(nblk), dim3(256), 0, stream, dY, X, mean, rstd, gamma, resid, dX, part, rows, cols); break;
-            case 2: hipLaunchKernelGGL(layernorm_bwd_v4_kernel<2>, dim3(nblk), dim3(256), 0, stream, dY, X, mean, rstd, gamma, resid, dX, part, rows, cols); break;
-            case 3: hipLaunchKernelGGL(layernorm_bwd_v4_kernel<3>, dim3(nblk), dim3(256), 0, stream, dY, X, mean, rstd, gamma, resid, dX, part, rows, cols); break;
-            default: hipLaunchKernelGGL(layernorm_bwd_v4_kernel<4>, dim3(nblk), dim3(256), 0, stream, dY, X, mean, rstd, gamma, resid, dX, part, rows, cols); break;
+            case 1: VSOM_LAUNCH(layernorm_bwd_v4_kernel<1>, dim3(nblk), dim3(256), 0, stream, dY, X, mean, rstd, gamma, resid, dX, part, rows, cols); break;
+            case 2: VSOM_LAUNCH(layernorm_bwd_v4_kernel<2>, dim3(nblk), dim3(256), 0, stream, dY, X, mean, rstd, gamma, resid, dX, part, rows, cols); break;
+            case 3: VSOM_LAUNCH(layernorm_bwd_v4_kernel<3>, dim3(nblk), dim3(256), 0, stream, dY, X, mean, rstd, gamma, resid, dX, part, rows, cols); break;
+            default: VSOM_LAUNCH(layernorm_bwd_v4_kernel<4>, dim3(nblk), dim3(256), 0, stream, dY, X, mean, rstd, gamma, resid, dX, part, rows, cols); break;
         }
     } else if (cols <= 256)
-        hipLaunchKernelGGL(layernorm_bwd_kernel<4>, dim3(nblk), dim3(256), shmem, stream, dY, X, mean, rstd, gamma, resid, dX, part, rows, cols);
+        VSOM_LAUNCH(layernorm_bwd_kernel<4>, dim3(nblk), dim3(256), shmem, stream, dY, X, mean, rstd, gamma, resid, dX, part, rows, cols);
     else
-        hipLaunchKernelGGL(layernorm_bwd_kernel<16>, dim3(nblk), dim3(256), shmem, stream, dY, X, mean, rstd, gamma, resid, dX, part, rows, cols);
+        VSOM_LAUNCH(layernorm_bwd_kernel<16>, dim3(nblk), dim3(256), shmem, stream, dY, X, mean, rstd, gamma, resid, dX, part, rows, cols);
     int rc = hip_status(hipGetLastError(), "layernorm_bwd_kernel");
     if (rc) return rc;
     return reduce_slabs2_internal(part, 2L * cols, nblk, dgamma, cols, dbeta, cols, cols, stream);

@@ -261,14 +261,14 @@ extern "C" {
 int vsom_fill(float* p, long n, float value, vsom_stream_t stream) {
     VSOM_REQUIRE(p && n >= 0, VSOM_EINVAL, "fill: bad arguments");
     if (n == 0) return VSOM_OK;
-    hipLaunchKernelGGL(fill_kernel, dim3(grid_for(n, 1024, 4096)), dim3(256), 0, stream, p, n, value);
+    VSOM_LAUNCH(fill_kernel, dim3(grid_for(n, 1024, 4096)), dim3(256), 0, stream, p, n, value);
     VSOM_LAUNCH_CHECK("fill_kernel");
 }
 
 int vsom_scale_by(float* p, long n, const float* scale_dev, vsom_stream_t stream) {
     VSOM_REQUIRE(p && scale_dev && n >= 0, VSOM_EINVAL, "scale_by: bad arguments");
     if (n == 0) return VSOM_OK;
-    hipLaunchKernelGGL(scale_by_kernel, dim3(grid_for(n, 1024, 4096)), dim3(256), 0, stream, p, n, scale_dev);
+    VSOM_LAUNCH(scale_by_kernel, dim3(grid_for(n, 1024, 4096)), dim3(256), 0, stream, p, n, scale_dev);
     VSOM_LAUNCH_CHECK("scale_by_kernel");
 }
 
@@ -276,20 +276,20 @@ int vsom_scaled_mul(float* out, const float* a, const float* b, long n, const fl
                     vsom_stream_t stream) {
     VSOM_REQUIRE(out && a && n >= 0, VSOM_EINVAL, "scaled_mul: bad arguments");
     if (n == 0) return VSOM_OK;
-    hipLaunchKernelGGL(scaled_mul_kernel, dim3(grid_for(n, 1024, 4096)), dim3(256), 0, stream, out, a, b, n, scale_dev, factor);
+    VSOM_LAUNCH(scaled_mul_kernel, dim3(grid_for(n, 1024, 4096)), dim3(256), 0, stream, out, a, b, n, scale_dev, factor);
     VSOM_LAUNCH_CHECK("scaled_mul_kernel");
 }
 
 int vsom_lincomb2(float* out, const float* a, float ca, const float* b, float cb, int64_t* counter, vsom_stream_t stream) {
     VSOM_REQUIRE(out && a && b, VSOM_EINVAL, "lincomb2: null pointer");
-    hipLaunchKernelGGL(lincomb2_kernel, dim3(1), dim3(64), 0, stream, out, a, ca, b, cb, reinterpret_cast<long long*>(counter));
+    VSOM_LAUNCH(lincomb2_kernel, dim3(1), dim3(64), 0, stream, out, a, ca, b, cb, reinterpret_cast<long long*>(counter));
     VSOM_LAUNCH_CHECK("lincomb2_kernel");
 }
 
 int vsom_loss_parts(float* parts, const float* main_sum, float main_scale, const float* som_sum, float som_coef, float som_scale,
                     int64_t* counter, vsom_stream_t stream) {
     VSOM_REQUIRE(parts && main_sum && som_sum, VSOM_EINVAL, "loss_parts: null pointer");
-    hipLaunchKernelGGL(loss_parts_kernel, dim3(1), dim3(64), 0, stream, parts, main_sum, main_scale, som_sum, som_coef, som_scale,
+    VSOM_LAUNCH(loss_parts_kernel, dim3(1), dim3(64), 0, stream, parts, main_sum, main_scale, som_sum, som_coef, som_scale,
                        reinterpret_cast<long long*>(counter));
     VSOM_LAUNCH_CHECK("loss_parts_kernel");
 }
@@ -300,7 +300,7 @@ int vsom_transpose_many(const float* src_base, float* dst_base, const long long*
     if (count == 0) return VSOM_OK;
     VSOM_REQUIRE(count <= 65535, VSOM_EINVAL, "transpose_many: more than 65535 tensors");
     dim3 grid(cdiv(max_rows, 32) * cdiv(max_cols, 32), count);
-    hipLaunchKernelGGL(transpose_many_kernel, grid, dim3(256), 0, stream, src_base, dst_base, table);
+    VSOM_LAUNCH(transpose_many_kernel, grid, dim3(256), 0, stream, src_base, dst_base, table);
     VSOM_LAUNCH_CHECK("transpose_many_kernel");
 }
 
@@ -311,7 +311,7 @@ int vsom_patch_embed_fwd(const float* img, const float* Wpe, const float* bpe, c
     VSOM_REQUIRE(B > 0 && C > 0 && S > 0 && p > 0 && E > 0 && S % p == 0, VSOM_EINVAL, "patch_embed_fwd: bad shape");
     const int g = S / p, n = g * g, Ntok = n + 1, pd = C * p * p;
     const long total = (long)B * C * S * S;
-    hipLaunchKernelGGL(patch_gather_kernel, dim3(cdiv(total, 256)), dim3(256), 0, stream, img, xp_ws, total, C, S, p, g);
+    VSOM_LAUNCH(patch_gather_kernel, dim3(cdiv(total, 256)), dim3(256), 0, stream, img, xp_ws, total, C, S, p, g);
     int rc = hip_status(hipGetLastError(), "patch_gather_kernel");
     if (rc) return rc;
     // tokens[b, 1+pi, :] = xp[b*n+pi, :] Wpe^T + bpe + pos[1+pi, :]
@@ -322,7 +322,7 @@ int vsom_patch_embed_fwd(const float* img, const float* Wpe, const float* bpe, c
     q.c_seg = n; q.c_stride = Ntok; q.c_off = 1;
     rc = launch_gemm(true, true, EPI_BIAS_RES, q, 1, stream);
     if (rc) return rc;
-    hipLaunchKernelGGL(cls_rows_kernel, dim3(cdiv((long)B * E, 256)), dim3(256), 0, stream, cls_token, pos, tokens, B, Ntok, E);
+    VSOM_LAUNCH(cls_rows_kernel, dim3(cdiv((long)B * E, 256)), dim3(256), 0, stream, cls_token, pos, tokens, B, Ntok, E);
     VSOM_LAUNCH_CHECK("cls_rows_kernel");
 }
 
@@ -343,7 +343,7 @@ int vsom_patch_embed_bwd(const float* dtokens, const float* xp_ws, float* dWpe, 
     const int M = B * n;
     int rc = linear_bwd_weight_impl(dtokens, E, xp_ws, pd, dWpe, dbpe, M, E, pd, n, Ntok, 1, ws, ws_bytes, stream);
     if (rc) return rc;
-    hipLaunchKernelGGL(cls_grad_kernel, dim3(cdiv(E, 32)), dim3(256), 0, stream, dtokens, dcls_token, B, Ntok, E);
+    VSOM_LAUNCH(cls_grad_kernel, dim3(cdiv(E, 32)), dim3(256), 0, stream, dtokens, dcls_token, B, Ntok, E);
     VSOM_LAUNCH_CHECK("cls_grad_kernel");
 }
 
@@ -361,7 +361,7 @@ int vsom_l1_loss(const float* pred, const float* target, float* loss_sum, float*
     VSOM_REQUIRE(ws && ws_bytes >= vsom_l1_loss_workspace_bytes(n), VSOM_EWORKSPACE, "l1_loss: workspace too small");
     const int nblk = l1_blocks(n);
     float* part = static_cast<float*>(ws);
-    hipLaunchKernelGGL(l1_loss_kernel, dim3(nblk), dim3(256), 0, stream, pred, target, part, dpred, grad_scale, n);
+    VSOM_LAUNCH(l1_loss_kernel, dim3(nblk), dim3(256), 0, stream, pred, target, part, dpred, grad_scale, n);
     int rc = hip_status(hipGetLastError(), "l1_loss_kernel");
     if (rc) return rc;
     return sum_partials(part, nblk, loss_sum, stream);
@@ -377,7 +377,7 @@ int vsom_l1_unpatchify(const float* pred, const float* img, float* recon, float*
     const long total = (long)B * (g * g + 1) * p * p * C;
     const int nblk = l1_blocks(total);
     float* part = static_cast<float*>(ws);
-    hipLaunchKernelGGL(l1_unpatchify_kernel, dim3(nblk), dim3(256), 0, stream, pred, img, recon, part, dpred, grad_scale,
+    VSOM_LAUNCH(l1_unpatchify_kernel, dim3(nblk), dim3(256), 0, stream, pred, img, recon, part, dpred, grad_scale,
                        total, C, S, p, g);
     int rc = hip_status(hipGetLastError(), "l1_unpatchify_kernel");
     if (rc) return rc;
@@ -392,7 +392,7 @@ int vsom_cross_entropy_ls(const float* logits, const int64_t* y, float smoothing
     VSOM_REQUIRE(B > 0 && C > 0, VSOM_EINVAL, "cross_entropy_ls: bad shape");
     VSOM_REQUIRE(ws && ws_bytes >= vsom_cross_entropy_ls_workspace_bytes(B), VSOM_EWORKSPACE, "cross_entropy_ls: workspace too small");
     float* part = static_cast<float*>(ws);
-    hipLaunchKernelGGL(ce_ls_kernel, dim3(cdiv(B, 4)), dim3(256), 0, stream, logits, y, smoothing, part, dlogits,
+    VSOM_LAUNCH(ce_ls_kernel, dim3(cdiv(B, 4)), dim3(256), 0, stream, logits, y, smoothing, part, dlogits,
                        grad_scale, B, C);
     int rc = hip_status(hipGetLastError(), "ce_ls_kernel");
     if (rc) return rc;
@@ -411,7 +411,7 @@ int vsom_adamw_step(float* p, const float* g, float* m, float* v, const float* w
     const float step_size = (float)((double)lr / bc1);
     const float inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
     const long n4 = n / 4;
-    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n4, 256, 8192)), dim3(256), 0, stream, p, g, m, v, wd_per_chunk, n4,
+    VSOM_LAUNCH(adamw_kernel, dim3(grid_for(n4, 256, 8192)), dim3(256), 0, stream, p, g, m, v, wd_per_chunk, n4,
                        lr, beta1, beta2, eps, step_size, inv_bc2_sqrt, grad_scale, adamw);
     VSOM_LAUNCH_CHECK("adamw_kernel");
 }
@@ -459,14 +459,14 @@ int vsom_contingency(const int64_t* a, const int64_t* b, long n, int na, int nb,
     VSOM_REQUIRE(a && b && table && out_of_range, VSOM_EINVAL, "contingency: null pointer");
     VSOM_REQUIRE(n >= 0 && na > 0 && nb > 0, VSOM_EINVAL, "contingency: bad sizes");
     if (n == 0) return VSOM_OK;
-    hipLaunchKernelGGL(vsom::contingency_kernel, dim3(vsom::grid_for(n, 256, 2048)), dim3(256), 0, stream, a, b, n, na, nb,
+    VSOM_LAUNCH(vsom::contingency_kernel, dim3(vsom::grid_for(n, 256, 2048)), dim3(256), 0, stream, a, b, n, na, nb,
                        table, out_of_range);
     VSOM_LAUNCH_CHECK("contingency_kernel");
 }
 
 int vsom_argmax_rows(const float* X, long ldx, int rows, int cols, int64_t* out, vsom_stream_t stream) {
     VSOM_REQUIRE(X && out && rows > 0 && cols > 0 && ldx >= cols, VSOM_EINVAL, "argmax_rows: bad arguments");
-    hipLaunchKernelGGL(vsom::argmax_rows_kernel, dim3(vsom::cdiv(rows, 4)), dim3(256), 0, stream, X, ldx, rows, cols, out);
+    VSOM_LAUNCH(vsom::argmax_rows_kernel, dim3(vsom::cdiv(rows, 4)), dim3(256), 0, stream, X, ldx, rows, cols, out);
     VSOM_LAUNCH_CHECK("argmax_rows_kernel");
 }
 

@@ -221,13 +221,13 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restri
 
 int bmu_finalize_plain(const float* slab, long slab_stride, int nslabs, float* dist, int64_t* bmu, int B, int K,
                        hipStream_t stream) {
-    hipLaunchKernelGGL(bmu_finalize_kernel, dim3(B), dim3(256), 0, stream, slab, slab_stride, nslabs, (const float*)nullptr,
+    VSOM_LAUNCH(bmu_finalize_kernel, dim3(B), dim3(256), 0, stream, slab, slab_stride, nslabs, (const float*)nullptr,
                        (const float*)nullptr, dist, bmu, K, 2);
     VSOM_LAUNCH_CHECK("bmu_finalize_kernel");
 }
 
 int sum_partials(const float* part, int n, float* out, hipStream_t stream) {
-    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, stream, part, n, out);
+    VSOM_LAUNCH(sum_partials_kernel, dim3(1), dim3(256), 0, stream, part, n, out);
     VSOM_LAUNCH_CHECK("sum_partials_kernel");
 }
 
@@ -242,10 +242,10 @@ int vsom_row_inv_norm(const float* X, long ldx, int rows, int cols, float eps, f
     VSOM_REQUIRE(X && inv_norm && rows > 0 && cols > 0 && ldx >= cols, VSOM_EINVAL, "row_inv_norm: bad arguments");
     const int vec = aligned16(X) && (ldx % 4 == 0);
     if (vec && cols % 4 == 0 && cols >= 4096) {
-        hipLaunchKernelGGL(row_inv_norm_wide_kernel, dim3(rows), dim3(256), 0, stream, X, ldx, cols, eps, inv_norm, 0);
+        VSOM_LAUNCH(row_inv_norm_wide_kernel, dim3(rows), dim3(256), 0, stream, X, ldx, cols, eps, inv_norm, 0);
         VSOM_LAUNCH_CHECK("row_inv_norm_wide_kernel");
     }
-    hipLaunchKernelGGL(row_inv_norm_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, stream, X, ldx, rows, cols, eps,
+    VSOM_LAUNCH(row_inv_norm_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, stream, X, ldx, rows, cols, eps,
                        inv_norm, vec, 0);
     VSOM_LAUNCH_CHECK("row_inv_norm_kernel");
 }
@@ -254,10 +254,10 @@ int vsom_row_sqnorm(const float* X, long ldx, int rows, int cols, float* sqnorm,
     VSOM_REQUIRE(X && sqnorm && rows > 0 && cols > 0 && ldx >= cols, VSOM_EINVAL, "row_sqnorm: bad arguments");
     const int vec = aligned16(X) && (ldx % 4 == 0);
     if (vec && cols % 4 == 0 && cols >= 4096) {
-        hipLaunchKernelGGL(row_inv_norm_wide_kernel, dim3(rows), dim3(256), 0, stream, X, ldx, cols, 0.f, sqnorm, 1);
+        VSOM_LAUNCH(row_inv_norm_wide_kernel, dim3(rows), dim3(256), 0, stream, X, ldx, cols, 0.f, sqnorm, 1);
         VSOM_LAUNCH_CHECK("row_inv_norm_wide_kernel");
     }
-    hipLaunchKernelGGL(row_inv_norm_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, stream, X, ldx, rows, cols, 0.f, sqnorm,
+    VSOM_LAUNCH(row_inv_norm_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, stream, X, ldx, rows, cols, 0.f, sqnorm,
                        vec, 1);
     VSOM_LAUNCH_CHECK("row_inv_norm_kernel");
 }
@@ -286,7 +286,7 @@ int vsom_bmu_cosine_finalize(const void* ws, size_t ws_bytes, const float* inv_n
     VSOM_REQUIRE(B > 0 && K > 0 && L > 0, VSOM_EINVAL, "bmu_cosine_finalize: bad shape");
     VSOM_REQUIRE(ws && ws_bytes >= vsom_bmu_cosine_workspace_bytes(B, K, L), VSOM_EWORKSPACE,
                  "bmu_cosine_finalize: workspace too small");
-    hipLaunchKernelGGL(bmu_finalize_kernel, dim3(B), dim3(256), 0, stream, (const float*)ws, (long)B * K,
+    VSOM_LAUNCH(bmu_finalize_kernel, dim3(B), dim3(256), 0, stream, (const float*)ws, (long)B * K,
                        bmu_splits(B, K, L), inv_nx, inv_nw, dist, bmu, K, 0);
     VSOM_LAUNCH_CHECK("bmu_finalize_kernel");
 }
@@ -296,7 +296,7 @@ int vsom_bmu_euclid_fwd(const float* X, long ldx, const float* W, const float* s
     VSOM_REQUIRE(sq_x && sq_w && bmu, VSOM_EINVAL, "bmu_euclid_fwd: null pointer");
     int rc = vsom_bmu_cosine_dots(X, ldx, W, B, K, L, ws, ws_bytes, stream);      // the same X.W^T contraction
     if (rc) return rc;
-    hipLaunchKernelGGL(bmu_finalize_kernel, dim3(B), dim3(256), 0, stream, (const float*)ws, (long)B * K,
+    VSOM_LAUNCH(bmu_finalize_kernel, dim3(B), dim3(256), 0, stream, (const float*)ws, (long)B * K,
                        bmu_splits(B, K, L), sq_x, sq_w, dist, bmu, K, 1);
     VSOM_LAUNCH_CHECK("bmu_finalize_kernel");
 }
@@ -327,14 +327,14 @@ int vsom_som_neigh_loss(const float* dist, const int64_t* bmu, const float* grid
                  "som_neigh_loss: backward outputs need coef, row_dot, col_dot (and inv_nx, inv_nw for cosine) together");
     const float inv_2T2 = (float)(1.0 / (2.0 * (double)T * (double)T));
     float* part = static_cast<float*>(ws);
-    hipLaunchKernelGGL(som_neigh_row_kernel, dim3(B), dim3(256), 0, stream, dist, bmu, grid, inv_2T2, inv_nx, inv_nw,
+    VSOM_LAUNCH(som_neigh_row_kernel, dim3(B), dim3(256), 0, stream, dist, bmu, grid, inv_2T2, inv_nx, inv_nw,
                        grad_scale, h, coef, row_dot, part, K, euclid, (const float*)nullptr);
     int rc = hip_status(hipGetLastError(), "som_neigh_row_kernel");
     if (rc) return rc;
     rc = sum_partials(part, B, loss_sum, stream);
     if (rc) return rc;
     if (bwd && euclid != 2) {
-        hipLaunchKernelGGL(som_neigh_col_kernel, dim3(cdiv(K, 32)), dim3(NCOL_RG * 32), 0, stream, dist, bmu, grid, inv_2T2,
+        VSOM_LAUNCH(som_neigh_col_kernel, dim3(cdiv(K, 32)), dim3(NCOL_RG * 32), 0, stream, dist, bmu, grid, inv_2T2,
                            inv_nw, grad_scale, col_dot, B, K, euclid, (const float*)nullptr);
         rc = hip_status(hipGetLastError(), "som_neigh_col_kernel");
     }
@@ -354,14 +354,14 @@ int vsom_som_weighted_loss(const float* dist, const float* weights, const float*
     VSOM_REQUIRE(!bwd || (euclid == 2 && coef) || (coef && row_dot && col_dot && (euclid || (inv_nx && inv_nw))), VSOM_EINVAL,
                  "som_weighted_loss: backward outputs need coef, row_dot, col_dot (and inv_nx, inv_nw for cosine) together");
     float* part = static_cast<float*>(ws);
-    hipLaunchKernelGGL(som_neigh_row_kernel, dim3(B), dim3(256), 0, stream, dist, (const int64_t*)nullptr, (const float*)nullptr,
+    VSOM_LAUNCH(som_neigh_row_kernel, dim3(B), dim3(256), 0, stream, dist, (const int64_t*)nullptr, (const float*)nullptr,
                        0.f, inv_nx, inv_nw, grad_scale, (float*)nullptr, coef, row_dot, part, K, euclid, weights);
     int rc = hip_status(hipGetLastError(), "som_neigh_row_kernel");
     if (rc) return rc;
     rc = sum_partials(part, B, loss_sum, stream);
     if (rc) return rc;
     if (bwd && euclid != 2) {
-        hipLaunchKernelGGL(som_neigh_col_kernel, dim3(cdiv(K, 32)), dim3(NCOL_RG * 32), 0, stream, dist, (const int64_t*)nullptr,
+        VSOM_LAUNCH(som_neigh_col_kernel, dim3(cdiv(K, 32)), dim3(NCOL_RG * 32), 0, stream, dist, (const int64_t*)nullptr,
                            (const float*)nullptr, 0.f, inv_nw, grad_scale, col_dot, B, K, euclid, weights);
         rc = hip_status(hipGetLastError(), "som_neigh_col_kernel");
     }

@@ -226,7 +226,7 @@ int vsom_bmu_manhattan_fwd(const float* X, long ldx, const float* W, float* dist
     const int s = l1_splits(B, K, L);
     const int per = cdiv(cdiv(L, 32), s);
     dim3 grid(cdiv(B, 64) * cdiv(K, 64), s);
-    hipLaunchKernelGGL(l1_dist_kernel, grid, dim3(256), 0, stream, X, ldx, W, static_cast<float*>(ws), (long)B * K, B, K, L,
+    VSOM_LAUNCH(l1_dist_kernel, grid, dim3(256), 0, stream, X, ldx, W, static_cast<float*>(ws), (long)B * K, B, K, L,
                        per, (int)(aligned16(X) && ldx % 4 == 0), (int)(aligned16(W) && L % 4 == 0));
     int rc = hip_status(hipGetLastError(), "l1_dist_kernel");
     if (rc) return rc;
@@ -238,10 +238,10 @@ int vsom_som_bwd_manhattan(const float* X, long ldx, const float* W, const float
     VSOM_REQUIRE(X && W && coef && gW && gX, VSOM_EINVAL, "som_bwd_manhattan: null pointer");
     VSOM_REQUIRE(B > 0 && K > 0 && L > 0 && ldx >= L && ldgx >= L, VSOM_EINVAL, "som_bwd_manhattan: bad shape");
     const int vx = aligned16(X) && ldx % 4 == 0, vw = aligned16(W) && L % 4 == 0, vc = aligned16(coef) && K % 4 == 0;
-    hipLaunchKernelGGL(l1_bwd_w_kernel, dim3(cdiv(K, 64) * cdiv(L, 64)), dim3(256), 0, stream, X, ldx, W, coef, gW, B, K, L, vx, vc);
+    VSOM_LAUNCH(l1_bwd_w_kernel, dim3(cdiv(K, 64) * cdiv(L, 64)), dim3(256), 0, stream, X, ldx, W, coef, gW, B, K, L, vx, vc);
     int rc = hip_status(hipGetLastError(), "l1_bwd_w_kernel");
     if (rc) return rc;
-    hipLaunchKernelGGL(l1_bwd_x_kernel, dim3(cdiv(B, 64) * cdiv(L, 64)), dim3(256), 0, stream, X, ldx, W, coef, gX, ldgx,
+    VSOM_LAUNCH(l1_bwd_x_kernel, dim3(cdiv(B, 64) * cdiv(L, 64)), dim3(256), 0, stream, X, ldx, W, coef, gX, ldgx,
                        accumulate_gx, B, K, L, vw, vc);
     VSOM_LAUNCH_CHECK("l1_bwd_x_kernel");
 }

@@ -22,7 +22,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from ._lib import on_stream
+from ._lib import Event, on_stream, stream_wait_stream
 from .arena import ParamArena
 from .tuning import hooks
 
@@ -293,9 +293,7 @@ class ViTAutoencoder(nn.Module):
                         Lh.__dict__[k] = v[h * Bh:(h + 1) * Bh] if k == "lse" else v[h * Th:(h + 1) * Th]
                     return Lh
                 cuts = a.__dict__["_enc_halves"] = [[cut(L, h) for L in a.enc] for h in (0, 1)]
-            ev = self._event()
-            ev.record()
-            side.wait_event(ev)
+            self._event().record().wait(side)
             # All blocks by default (A/B in one process, round 2: 0 / 6 / 12 of 12 blocks split -> 11.77 / 11.81 /
             # 11.68 ms per step; round 1 kept it to half because the f32-MFMA BMU pass ran slower right after a dense
             # forward -- the bf16 BMU pass does not).
@@ -308,9 +306,7 @@ class ViTAutoencoder(nn.Module):
                 c0 = self._block_fwd(self.blocks[i], cuts[0][i], c0, Bh, a.N)
                 with on_stream(side):
                     c1 = self._block_fwd(self.blocks[i], cuts[1][i], c1, Bh, a.N)
-            ev2 = self._event()
-            ev2.record(side)
-            torch.cuda.current_stream().wait_event(ev2)
+            self._event().record(side).wait()
             cur = a.enc[nsplit - 1].x2 if nsplit > 0 else a.tok0
             for blk, L in zip(self.blocks[nsplit:], a.enc[nsplit:]):
                 cur = self._block_fwd(blk, L, cur, a.B, a.N)
@@ -441,21 +437,15 @@ class ViTAutoencoder(nn.Module):
     _side = None
 
     def _event(self):
-        """Pooled events (re-recording one is safe once the waits on its previous record are enqueued)."""
-        pool = self.__dict__.setdefault("_ev_pool", [])
-        i = self.__dict__.get("_ev_next", 0)
-        if len(pool) < 64:
-            pool.append(torch.cuda.Event())
-        self.__dict__["_ev_next"] = (i + 1) % 64
-        return pool[i % len(pool)]
+        """Pooled library events (re-recording one is safe once the waits on its previous record are enqueued; the pool is
+        far longer than the few events whose wait is deferred by a block or two)."""
+        return Event.pooled()
 
     def _dw(self, dy, x, gw, gb):
         side = self._side
         if side is None:
             return ops.linear_bwd_weight(dy, x, gw, gb)
-        ev = self._event()
-        ev.record()                              # on the main (current) stream: dy is final here
-        side.wait_event(ev)
+        self._event().record().wait(side)       # recorded on the main (current) stream: dy is final here
         with on_stream(side):
             ops.linear_bwd_weight(dy, x, gw, gb)
 
@@ -466,13 +456,11 @@ class ViTAutoencoder(nn.Module):
             pend.clear()
             return
         while len(pend) > keep:
-            torch.cuda.current_stream().wait_event(pend.pop(0))
+            pend.pop(0).wait()
 
     def _side_mark(self):
         if self._side is not None:
-            ev = self._event()
-            ev.record(self._side)
-            self.__dict__.setdefault("_side_pending", []).append(ev)
+            self.__dict__.setdefault("_side_pending", []).append(self._event().record(self._side))
 
     def _block_bwd(self, blk: Block, L: _Acts, x_in, gout, a: _Acts, G, prefix: str, bufs, WT=None, parity: int = 0):
         """gout: gradient w.r.t. the block output [T,dim]; returns gradient w.r.t. x_in (in bufs)."""
@@ -759,7 +747,8 @@ class SOMLayer(_Base):
         s.reranked = torch.zeros(1, dtype=torch.int32, device=device)      # rows whose BMU needed the exact re-rank (cumulative)
         s.coef, s.row_dot, s.col_dot = f(B, K), f(B), f(K)
         s.loss_sum = f(1)
-        self._bufs = {B: s}
+        # like the ViT's activation buffers: at most two batch sizes stay allocated (training and validation batches alternate)
+        self._bufs = dict(list(self._bufs.items())[-1:] + [(B, s)])
         return s
 
     # reference API -----------------------------------------------------------------------
@@ -943,7 +932,12 @@ class _StepLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, anchor, model, x, y, gamma_t, T):
         ctx.model = model
-        out = model._forward_losses(x, y, gamma_t, T, want_grad=True).clone()
+        ctx.taped = hasattr(model, "_tape_usable") and model._tape_usable(x)
+        if ctx.taped:
+            out, ctx.backward_done = model._taped_forward(x, y, gamma_t, T)
+            out = out.clone()
+        else:
+            out = model._forward_losses(x, y, gamma_t, T, want_grad=True).clone()
         ctx.forward_id = model._forward_id
         return out
 
@@ -954,10 +948,34 @@ class _StepLoss(torch.autograd.Function):
             raise RuntimeError("ViTSOM: backward() called twice for one training_step (or after a later forward): the "
                                "step's buffers and gradient seeds are single-use; gradient accumulation is not supported")
         m._seeds_consumed = True
-        m._scale_seeds(gout)               # 1.0 under a plain loss.backward()
-        m._backward()
+        if ctx.taped and m._ctx[1].__dict__.get("tape") is not None:
+            m._taped_backward(gout)        # segment 2 scales the seeds by gout, segment 3 is the backward
+        else:
+            m._scale_seeds(gout)           # 1.0 under a plain loss.backward()
+            m._backward()
         m._expose_grads()
         return None, None, None, None, None, None
+
+
+class _StepTape:
+    """Handle of a recorded step (vsom_tape_*): destroyed with the activation buffers it points into."""
+
+    def __init__(self, tid, nseg, key, started, comm_dirty, side, som_bufs):
+        if nseg != 4:
+            ops.tape_destroy(tid)
+            raise RuntimeError(f"launch tape: expected 4 segments, recorded {nseg}")
+        self.id, self.key, self.started, self.comm_dirty, self.side, self.som_bufs = tid, key, started, comm_dirty, side, som_bufs
+
+    def close(self):
+        if self.id:
+            ops.tape_destroy(self.id)
+            self.id = 0
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def init_vsom_comm(world_size: int, rank: int, unique_id: Optional[bytes] = None):
@@ -1076,7 +1094,7 @@ class _ArenaOwner:
         for w in getattr(self, "_works", ()):
             w.wait()
         if getattr(self, "_comm_dirty", False) and self.arena is not None and self.arena.grads.is_cuda:
-            torch.cuda.current_stream().wait_stream(self._comm)
+            stream_wait_stream(None, self._comm)
         self._works, self._started, self._comm_dirty = [], [], False
 
     def _arena_span(self, first: str, last: str):
@@ -1096,7 +1114,7 @@ class _ArenaOwner:
             if comm is None or comm.device != g.device:
                 comm = self._comm = torch.cuda.Stream(device=g.device)
             for ev in after:
-                comm.wait_event(ev)
+                ev.wait(comm)
             if self._use_vsom_comm:
                 # the library's own RCCL communicator (vsom_comm_*): the collective is enqueued on `comm` like a kernel
                 with on_stream(comm):
@@ -1116,9 +1134,7 @@ class _ArenaOwner:
         evs = []
         if self.arena.grads.is_cuda:
             for st in streams:
-                ev = torch.cuda.Event()
-                ev.record(st)
-                evs.append(ev)
+                evs.append(Event.pooled().record(st))
         self._reduce_async(lo, hi, evs)
 
     def allreduce_gradients(self):
@@ -1132,9 +1148,7 @@ class _ArenaOwner:
             self._exchange_reset()
         evs = []
         if g.is_cuda:
-            ev = torch.cuda.Event()
-            ev.record()                         # current stream: every gradient is final here
-            evs.append(ev)
+            evs.append(Event.pooled().record())     # current stream: every gradient is final here
         pos = 0
         for lo, hi in sorted(self._started) + [(g.numel(), g.numel())]:
             if lo > pos:
@@ -1307,48 +1321,61 @@ class ViTSOM(_ArenaOwner, _Base):
         x, a, s = self._run_forward(x, need_decoder=False)
         return s.bmu, (a.logits if self.classification else None)
 
-    @torch.no_grad()
-    def _forward_losses(self, x, y, gamma_t: float, T: float, want_grad: bool):
-        """All forward kernels + both losses (+ loss-side gradients when want_grad).  Returns the
-        total loss as a 0-dim device tensor; parts land in self._last."""
-        x, a, s = self._run_forward(x, need_decoder=not self.classification)
-        B, K = a.B, self.som_layer.n_prototypes
-        self._ctx = (x, a, s)
-        self._forward_id, self._seeds_consumed = self._forward_id + 1, False
-        dev = x.device
-        if not hasattr(a, "main_sum"):
-            a.main_sum = torch.empty(1, dtype=torch.float32, device=dev)
-            a.loss_ring = torch.zeros(_LOSS_RING, 4, dtype=torch.float32, device=dev)
-            a.loss_slot = 0
-        c = gamma_t / (B * K)
+    # The two calls of the step whose arguments change from step to step (temperature, gamma ramp): the host issues them
+    # itself, also when the rest of the step is replayed from a launch tape (tape holes).
+    def _call_neigh(self, s: _Acts, gamma_t: float, T: float, B: int, want_grad: bool):
+        K = self.som_layer.n_prototypes
         if want_grad:
             ops.som_neigh_loss(s.dist, s.bmu, self.som_layer.grid_positions, T, s.loss_sum, inv_nx=s.inx, inv_nw=s.inw,
-                               grad_scale=c, coef=s.coef, row_dot=s.row_dot, col_dot=s.col_dot,
+                               grad_scale=gamma_t / (B * K), coef=s.coef, row_dot=s.row_dot, col_dot=s.col_dot,
                                distance=self.som_layer._dist_mode)
         else:
             ops.som_neigh_loss(s.dist, s.bmu, self.som_layer.grid_positions, T, s.loss_sum,
                                distance=self.som_layer._dist_mode)
-        if self.classification:
-            yv = y.view(-1)
-            if yv.dtype != torch.int64:
-                yv = yv.long()
-            ops.cross_entropy_ls(a.logits, yv.contiguous(), self.smoothing, a.main_sum,
-                                 dlogits=a.dlogits if want_grad else None, grad_scale=1.0 / B)
-            main_scale = 1.0 / B
-        else:
-            ops.l1_unpatchify(a.pred, x, a.main_sum, dpred=a.dpred if want_grad else None, grad_scale=1.0 / x.numel(),
-                              p=self.vit.patch_embed.patch_size[0])
-            main_scale = 1.0 / x.numel()
+
+    def _call_parts(self, a: _Acts, s: _Acts, gamma_t: float, T: float, B: int, numel_x: int, want_grad: bool):
         # total = main + gamma_t * som (and the two terms by themselves, for logging) from the two device-side sums, in one
         # tiny kernel that also advances the `iteration` buffer of a training step (vit_som.py:104): no ATen kernel in
         # the step.  The three values land in their own slot of a small ring, so `_last` and the returned loss stay
         # valid for the next _LOSS_RING - 1 steps (plain tensors: .get / `in` / iteration / ** all see them).
+        K = self.som_layer.n_prototypes
+        main_scale = 1.0 / B if self.classification else 1.0 / numel_x
         a.loss_slot = (a.loss_slot + 1) % _LOSS_RING
         parts = a.loss_ring[a.loss_slot]
         ops.loss_parts(parts, a.main_sum, main_scale, s.loss_sum, gamma_t / (B * K), 1.0 / (B * K),
                        counter=self.iteration if want_grad else None)
         self._last = {"total": parts[0], "main": parts[1], "som": parts[2], "gamma_t": gamma_t, "T": T}
         return parts[0]
+
+    def _loss_buffers(self, a: _Acts, dev):
+        if not hasattr(a, "main_sum"):
+            a.main_sum = torch.empty(1, dtype=torch.float32, device=dev)
+            a.loss_ring = torch.zeros(_LOSS_RING, 4, dtype=torch.float32, device=dev)
+            a.loss_slot = 0
+
+    @torch.no_grad()
+    def _forward_losses(self, x, y, gamma_t: float, T: float, want_grad: bool):
+        """All forward kernels + both losses (+ loss-side gradients when want_grad).  Returns the
+        total loss as a 0-dim device tensor; parts land in self._last."""
+        x, a, s = self._run_forward(x, need_decoder=not self.classification)
+        B = a.B
+        self._ctx = (x, a, s)
+        self._forward_id, self._seeds_consumed = self._forward_id + 1, False
+        self._loss_buffers(a, x.device)
+        with ops.tape_hole():
+            self._call_neigh(s, gamma_t, T, B, want_grad)
+        if self.classification:
+            yv = y.view(-1)
+            if yv.dtype != torch.int64:
+                yv = yv.long()
+            ops.cross_entropy_ls(a.logits, yv.contiguous(), self.smoothing, a.main_sum,
+                                 dlogits=a.dlogits if want_grad else None, grad_scale=1.0 / B)
+        else:
+            ops.l1_unpatchify(a.pred, x, a.main_sum, dpred=a.dpred if want_grad else None, grad_scale=1.0 / x.numel(),
+                              p=self.vit.patch_embed.patch_size[0])
+        with ops.tape_hole():
+            total = self._call_parts(a, s, gamma_t, T, B, x.numel(), want_grad)
+        return total
 
     def _ensure_streams(self, device):
         """The two extra HIP streams of the step (kept to two: a process has few hardware queues)."""
@@ -1440,9 +1467,7 @@ class ViTSOM(_ArenaOwner, _Base):
             # d_xe; the decoder's last GEMM waits for it and accumulates on top.  The prototype
             # all-reduce is issued behind it: it starts the moment gW is final, before the decoder
             # backward has finished.
-            ev = self.vit._event()
-            ev.record()
-            side.wait_event(ev)
+            self.vit._event().record().wait(side)
             with on_stream(side):
                 ops.fill(a.d_xe, 0.0)
                 som_backward(gX, False)
@@ -1452,9 +1477,9 @@ class ViTSOM(_ArenaOwner, _Base):
             # (round-robin) event could have been re-recorded for something else (deep decoders)
             som_done = self.__dict__.get("_som_done_ev")
             if som_done is None:
-                som_done = self.__dict__["_som_done_ev"] = torch.cuda.Event()
+                som_done = self.__dict__["_som_done_ev"] = Event()
             som_done.record(side)
-            self.vit._decoder_bwd(a, Gv, self._WT, before_dxe=lambda: main.wait_event(som_done))
+            self.vit._decoder_bwd(a, Gv, self._WT, before_dxe=lambda: som_done.wait())
             if "decoder" in buckets:
                 self._reduce_early(*buckets["decoder"], streams=streams_now())
 
@@ -1465,7 +1490,7 @@ class ViTSOM(_ArenaOwner, _Base):
 
         self.vit._encoder_bwd(a, Gv, self._WT, on_block if buckets else None)
         if self.vit._side is not None:
-            main.wait_stream(self.vit._side)     # every gradient is final from here on
+            stream_wait_stream(None, self.vit._side)     # every gradient is final from here on
             self.vit.__dict__.setdefault("_side_pending", []).clear()
 
     # -- data-parallel exchange ----------------------------------------------------------------
@@ -1473,6 +1498,79 @@ class ViTSOM(_ArenaOwner, _Base):
     def _schedules_for_step(self):
         self.som_layer.update_temperature(self._it)                     # vit_som.py:84 (iteration BEFORE increment)
         return self._gamma_t(), float(self.som_layer.current_temperature)
+
+    # -- launch tape: the step's ~420 launches recorded once (while they run) and re-issued from C -------------------
+    # Segments: 0 = forward up to the distances, 1 = main loss, 2 = loss-seed scaling (autograd bridge only), 3 = the whole
+    # backward; the neighbourhood kernel and the loss combination sit in the holes between 0 | 1 | 2 and are issued from here
+    # with this step's temperature and gamma.  Inputs are staged into fixed buffers; every other buffer of the step is
+    # persistent per batch size, so the tape lives and dies with the activation buffers (`a`).
+    def _tape_key(self):
+        return (ops.get_gemm_mode(), hooks.side_stream, hooks.fwd_split, hooks.fwd_split_blocks, hooks.overlap_allreduce,
+                hooks.bucket_blocks, self.world_size, self._use_vsom_comm, id(self.arena))
+
+    def _tape_usable(self, x) -> bool:
+        return bool(hooks.launch_tape and x.is_cuda and (self.world_size == 1 or self._use_vsom_comm) and ops.tape_recording() == 0)
+
+    def _stage_inputs(self, x, y, a: _Acts):
+        if not hasattr(a, "x_in"):
+            a.x_in = torch.empty(a.B, self.vit.in_chans, self.vit.img_size, self.vit.img_size, dtype=torch.float32, device=a.device)
+            a.y_in = torch.zeros(a.B, dtype=torch.int64, device=a.device)
+            a.gout_in = torch.ones(1, dtype=torch.float32, device=a.device)
+            a.steps_seen = 0
+        a.x_in.copy_(x)
+        if self.classification:
+            a.y_in.copy_(y.view(-1))
+        return a.x_in, a.y_in
+
+    @torch.no_grad()
+    def _taped_forward(self, x, y, gamma_t: float, T: float):
+        """Forward + losses (+ the backward too while the tape is being recorded).  Returns (total, backward_done)."""
+        x = self.vit._check_input(x)
+        a = self.vit._buffers_for(x.shape[0], x.device)
+        xs, ys = self._stage_inputs(x, y, a)
+        tape = a.__dict__.get("tape")
+        # the tape holds raw pointers: it is valid only for the buffers (ViT activations `a`, SOM buffers `s`, arenas) and the
+        # switches it was recorded with
+        if tape is not None and (tape.key != self._tape_key() or tape.som_bufs is not self.som_layer._bufs.get(a.B)):
+            tape.close()
+            tape = a.tape = None
+        if tape is None:
+            a.steps_seen += 1
+            if a.steps_seen <= 2:                     # host-driven: scratch buffers and lazily built tables settle first
+                return self._forward_losses(xs, ys, gamma_t, T, want_grad=True), False
+            tid = ops.tape_begin()
+            try:
+                total = self._forward_losses(xs, ys, gamma_t, T, want_grad=True)          # segments 0 | hole | 1 | hole | 2 ...
+                a.gout_in.fill_(1.0)
+                self._scale_seeds(a.gout_in)                                              # ... segment 2 (x 1.0: exact no-op)
+                ops.tape_cut()
+                self._backward()                                                          # segment 3
+            finally:
+                nseg = ops.tape_end()
+            a.tape = _StepTape(tid, nseg, self._tape_key(), list(self._started), self._comm_dirty, self.vit._side, self._ctx[2])
+            return total, True
+        # replay: the host-side state a host-driven step leaves behind, then segment | hole | segment | hole
+        s = tape.som_bufs
+        a.version += 1
+        self._ctx = (xs, a, s)
+        self._forward_id, self._seeds_consumed = self._forward_id + 1, False
+        ops.tape_replay(tape.id, 0)
+        self._call_neigh(s, gamma_t, T, a.B, True)
+        ops.tape_replay(tape.id, 1)
+        return self._call_parts(a, s, gamma_t, T, a.B, xs.numel(), True), False
+
+    @torch.no_grad()
+    def _taped_backward(self, gout=None):
+        """The backward of the last taped forward (segment 3; segment 2 first when a loss seed other than 1 comes in)."""
+        _, a, _ = self._ctx
+        tape = a.tape
+        self._grads_reduced = False
+        self._exchange_reset()
+        if gout is not None:
+            a.gout_in.copy_(gout.detach().reshape(1))
+            ops.tape_replay(tape.id, 2)
+        ops.tape_replay(tape.id, 3)
+        self._started, self._comm_dirty, self.vit._side = list(tape.started), tape.comm_dirty, tape.side
 
     def training_step(self, batch, batch_idx):
         """vit_som.py:80-105.  Returns a scalar tensor; ``.backward()`` runs the HIP backward."""
@@ -1494,8 +1592,16 @@ class ViTSOM(_ArenaOwner, _Base):
         arena (the caller then runs optimizer.step()).  Returns the loss tensor."""
         self._estimated_steps()
         gamma_t, T = self._schedules_for_step()
-        total = self._forward_losses(x, y, gamma_t, T, want_grad=True)
-        self._backward()
+        if self._tape_usable(x):
+            total, backward_done = self._taped_forward(x, y, gamma_t, T)
+            if not backward_done:
+                if self._ctx[1].__dict__.get("tape") is not None:
+                    self._taped_backward()
+                else:
+                    self._backward()
+        else:
+            total = self._forward_losses(x, y, gamma_t, T, want_grad=True)
+            self._backward()
         self._advance()
         return total
 

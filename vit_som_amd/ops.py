@@ -508,3 +508,51 @@ def comm_allreduce_sum(t):
 
 def comm_destroy():
     check(lib.vsom_comm_destroy(), "vsom_comm_destroy")
+
+
+# ---------------------------------------------------------------- launch tape
+def tape_begin() -> int:
+    tid = int(lib.vsom_tape_begin())
+    if tid <= 0:
+        check(tid, "vsom_tape_begin")
+    return tid
+
+
+def tape_cut() -> int:
+    return int(lib.vsom_tape_cut())
+
+
+def tape_end() -> int:
+    return int(lib.vsom_tape_end())
+
+
+def tape_recording() -> int:
+    """0 = not recording, 1 = recording, 2 = recording but paused."""
+    return int(lib.vsom_tape_recording())
+
+
+class tape_hole:
+    """A call whose arguments change from step to step: executed but kept OFF the tape, which is cut around it (the host
+    re-issues it between two replayed segments).  A no-op when no tape is being recorded."""
+
+    def __enter__(self):
+        self.active = tape_recording() == 1
+        if self.active:
+            lib.vsom_tape_cut()
+            check(lib.vsom_tape_pause(1), "vsom_tape_pause")
+
+    def __exit__(self, *exc):
+        if self.active:
+            check(lib.vsom_tape_pause(0), "vsom_tape_pause")
+
+
+def tape_replay(tape: int, segment: int):
+    check(lib.vsom_tape_replay(int(tape), int(segment)), "vsom_tape_replay")
+
+
+def tape_segment_ops(tape: int, segment: int) -> int:
+    return int(lib.vsom_tape_segment_ops(int(tape), int(segment)))
+
+
+def tape_destroy(tape: int):
+    check(lib.vsom_tape_destroy(int(tape)), "vsom_tape_destroy")

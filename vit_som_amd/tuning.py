@@ -12,6 +12,7 @@ class _Hooks:
     fwd_split_blocks = None     # how many encoder blocks run as two chains (None = all)
     overlap_allreduce = True    # N > 1: issue the all-reduce pieces inside the backward pass
     bucket_blocks = 3           # encoder blocks per early all-reduce piece
+    launch_tape = True          # train_step_fused / training_step re-issue the recorded launches of a step from C (model.py)
 
     def set(self, **kw):
         for k, v in kw.items():
