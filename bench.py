@@ -112,7 +112,8 @@ def secondary_kernels(ops, B, dev):
     dW = torch.empty(3 * E, E, device=dev); db = torch.empty(3 * E, device=dev)
     dY = torch.randn(T, 3 * E, device=dev)
     t_dw = ms(lambda: ops.linear_bwd_weight(dY, x, dW, db))
-    split = ops.get_gemm_mode() == ops.GEMM_SPLIT_BF16
+    split = ops.get_gemm_mode() != ops.GEMM_F32
+    grad3 = ops.get_gemm_mode() == ops.GEMM_SPLIT_BF16_GRAD3
     lin_tf = 2.0 * T * 3 * E * E / (t_lin * 1e-3) / 1e12
     att_tf = 4.0 * B * H * N * N * (E // H) / (t_att * 1e-3) / 1e12
     attb_tf = 10.0 * B * H * N * N * (E // H) / (t_attb * 1e-3) / 1e12        # five N x N x hd products
@@ -132,7 +133,10 @@ def secondary_kernels(ops, B, dev):
                           "frac": round(attb_tf / F32_MFMA_PEAK_TFLOPS, 3), "peak_basis": "f32 MFMA (16x16x4); 10 B H N^2 hd FLOP",
                           "hbm_GBps": round(4.0 * (2 * T * 3 * E + 2 * T * E) / (t_attb * 1e-3) / 1e9, 1)},
         "linear_qkv_bwd_weight": {"shape": [3 * E, E, T], "ms": round(t_dw, 4), "achieved_f32_equiv_TFLOPs": round(dw_tf, 1),
-                                  "peak_TFLOPs": round(lin_peak, 1), "frac": round(dw_tf / lin_peak, 3),
+                                  "peak_TFLOPs": round(lin_peak * (2.0 if grad3 else 1.0), 1),
+                                  "frac": round(dw_tf / (lin_peak * (2.0 if grad3 else 1.0)), 3),
+                                  "peak_basis": ("dense bf16 MFMA 2500 TF / 3 products per fp32 product (two-piece split)" if grad3 else
+                                                 "dense bf16 MFMA 2500 TF / 6 products" if split else "f32 MFMA"),
                                   "note": "dW = dY^T X over the token rows incl. the fixed-order slab reduction and the bias gradient",
                                   "hbm_GBps": round(4.0 * (T * 3 * E + T * E + 3 * E * E) / (t_dw * 1e-3) / 1e9, 1)},
     }
@@ -145,7 +149,7 @@ def bmu_roofline(ops, B, world, bmu_ms, bmu_calls):
     K, L = 1600, 12288
     flops, nbytes = 2.0 * B * L * K, 4.0 * (B * L + K * L + B * K)       # 20.13 GFLOP, 107.1 MB at B = 512
     t_s = bmu_ms * 1e-3
-    split = ops.get_gemm_mode() == ops.GEMM_SPLIT_BF16
+    split = ops.get_gemm_mode() != ops.GEMM_F32
     # three bf16 products per fp32 product (two-piece split + exact re-rank) vs the exact-f32 MFMA engine
     peak = BF16_MFMA_PEAK_TFLOPS / 3.0 if split else F32_MFMA_PEAK_TFLOPS
     traffic = None
@@ -305,16 +309,22 @@ def main():
             "scaling": "weak", "vs_baseline": None,
             # fp32 storage / accumulation / results; the Linear GEMMs reach the bf16 matrix cores through an exact
             # 3-piece split of every fp32 operand (config.gemm_arithmetic), everything else is plain f32
-            "dtype": "f32" if ops.get_gemm_mode() == ops.GEMM_F32 else "f32 (Linear GEMMs: exact 3xbf16 operand split on bf16 MFMA)",
+            "dtype": ("f32" if ops.get_gemm_mode() == ops.GEMM_F32 else
+                      "f32 (Linear GEMMs on bf16 MFMA: forward from an exact 3xbf16 operand split, six products; " +
+                      ("weight / input gradients from a 2xbf16 split, three products, rel. error 4e-6)"
+                       if ops.get_gemm_mode() == ops.GEMM_SPLIT_BF16_GRAD3 else "gradients likewise)")),
             "data": "synthetic",
             "config": {"workload": "c3: vit_som CIFAR-10 shapes (3x32x32, patch 4, E=192, 3 heads, depth 12 + 2-layer "
                                    "decoder), 40x40 cosine SOM on the flattened patch tokens (L=12288), clustering loss "
                                    "L1(recon)+gamma*SOM, AdamW, random-init weights",
                        "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}",
-                       "gemm_arithmetic": ("fp32 in/out; nn.Linear GEMMs on bf16 MFMA from an EXACT 3-piece bf16 split of "
-                                           "each fp32 operand (6 products, fp32 accumulate; error <= fp32 MFMA's); "
+                       "gemm_arithmetic": ("fp32 in/out; forward nn.Linear GEMMs on bf16 MFMA from an EXACT 3-piece bf16 split of "
+                                           "each fp32 operand (6 products, fp32 accumulate; error <= fp32 MFMA's); " +
+                                           ("their weight- and input-gradient GEMMs from a 2-piece round-to-nearest split (3 "
+                                            "products; gradients of the whole step within 1.3e-5 relative of fp64, bar 1e-4); "
+                                            if ops.get_gemm_mode() == ops.GEMM_SPLIT_BF16_GRAD3 else "gradient GEMMs likewise; ") +
                                            "BMU distances from a 2-piece split (3 products, |err| <= 4.6e-5) with an exact "
-                                           "fp64 re-rank of the near-minimum prototypes") if ops.get_gemm_mode() == ops.GEMM_SPLIT_BF16
+                                           "fp64 re-rank of the near-minimum prototypes") if ops.get_gemm_mode() != ops.GEMM_F32
                                           else "f32 MFMA everywhere",
                        "final_loss": round(final_loss, 6)},
             "roofline": bmu_roofline(ops, B, world, bmu_ms, bmu_calls),

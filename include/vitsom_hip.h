@@ -84,17 +84,24 @@ int vsom_linear_bwd_input_t(const float* dY, long lddy, const float* Wt, float* 
 int vsom_transpose_many(const float* src_base, float* dst_base, const long long* table, int count,
                         int max_rows, int max_cols, vsom_stream_t stream);
 
-/* Arithmetic of the nn.Linear-shaped GEMMs (vsom_linear_*_fwd, vsom_linear_bwd_input_t,
- * vsom_patch_embed_fwd).  Both modes deliver fp32-accurate results from fp32 operands:
- *   VSOM_GEMM_F32        v_mfma_f32_32x32x2_f32, bitwise an fmaf chain;
- *   VSOM_GEMM_SPLIT_BF16 (default) every operand split exactly into three bf16 pieces, the six
- *                        leading cross products on v_mfma_f32_32x32x16_bf16 (csrc/gemm_x6.h):
- *                        dropped terms < 2^-22 relative, 2.7x fewer matrix-core cycles.
+/* Arithmetic of the nn.Linear-shaped GEMMs (vsom_linear_*_fwd, vsom_linear_bwd_input_t, vsom_linear_bwd_weight,
+ * vsom_patch_embed_*).  fp32 operands, fp32 accumulation and fp32 results in every mode:
+ *   VSOM_GEMM_F32              v_mfma_f32_32x32x2_f32, bitwise an fmaf chain;
+ *   VSOM_GEMM_SPLIT_BF16       every operand split EXACTLY into three bf16 pieces, the six leading cross products on
+ *                              v_mfma_f32_32x32x16_bf16 (csrc/gemm_x6.h): dropped terms < 2^-22 relative -- fp32-accurate,
+ *                              2.7x fewer matrix-core cycles than the f32 MFMA;
+ *   VSOM_GEMM_SPLIT_BF16_GRAD3 (default) forward GEMMs exactly as VSOM_GEMM_SPLIT_BF16 -- outputs, logits, distances and
+ *                              BMU indices are bit-identical to that mode -- while the Linear layers' weight-gradient and
+ *                              input-gradient GEMMs (vsom_linear_bwd_weight, vsom_linear_bwd_input_t) use the two-piece
+ *                              round-to-nearest split, three products: |error| <= 3 * 2^-16 per product in the worst case,
+ *                              4e-6 relative on a weight gradient, 1e-5 on the gradients of the whole 12 + 2-layer step
+ *                              (tools/accuracy_modes.py; the bar is 1e-4), half the matrix-core work of the backward GEMMs.
  * The cosine BMU pass has its own engines: vsom_bmu_cosine_x3_* (default: two-piece split, three products, exact
  * re-rank) and vsom_bmu_cosine_* (exact-f32 MFMA; what the host mirror uses in VSOM_GEMM_F32 mode and for the
  * euclidean distance).  Process-wide; returns VSOM_EINVAL on an unknown mode. */
 #define VSOM_GEMM_F32 0
 #define VSOM_GEMM_SPLIT_BF16 1
+#define VSOM_GEMM_SPLIT_BF16_GRAD3 2
 int vsom_set_gemm_mode(int mode);
 int vsom_get_gemm_mode(void);
 

@@ -38,15 +38,22 @@ def dev(t):
 # fp32 GEMM tolerance: relative Frobenius error vs an fp64 reference -- the SAME bound for the
 # exact-f32 MFMA engine and the split-bf16 engine (both are fp32-accurate)
 GEMM_TOL = 2e-6
+# the default mode's gradient GEMMs (vsom_linear_bwd_weight / _bwd_input_t): two-piece split, three products -- worst case
+# 3 * 2^-16 = 4.6e-5 per product, measured 4e-6 on random operands; the model-level gradient bar stays 1e-4
+GRAD3_TOL = 2e-5
 
 
-@pytest.fixture(params=["split_bf16", "f32"])
+@pytest.fixture(params=["grad3", "split_bf16", "f32"])
 def gemm_mode(request, ops):
-    """Run a test under both arithmetic modes of the nn.Linear-shaped GEMMs."""
+    """Run a test under every arithmetic mode of the nn.Linear-shaped GEMMs (grad3 = the default)."""
     prev = ops.get_gemm_mode()
-    ops.set_gemm_mode(ops.GEMM_SPLIT_BF16 if request.param == "split_bf16" else ops.GEMM_F32)
+    ops.set_gemm_mode({"grad3": ops.GEMM_SPLIT_BF16_GRAD3, "split_bf16": ops.GEMM_SPLIT_BF16, "f32": ops.GEMM_F32}[request.param])
     yield request.param
     ops.set_gemm_mode(prev)
+
+
+def grad_tol(mode):
+    return GRAD3_TOL if mode == "grad3" else GEMM_TOL
 
 
 @pytest.mark.parametrize("M,N,K,ldpad", [(70, 50, 48, 0), (300, 192, 192, 0), (257, 576, 192, 8), (33, 10, 24, 0),
@@ -116,17 +123,18 @@ def test_linear_bwd_input_t(ops, gemm_mode, M, N, K):
     table = torch.tensor([[0, 0, N, K]], dtype=torch.int64, device=DEV)
     ops.transpose_many(Wd, Wt.view(-1), table, N, K)
     assert torch.equal(Wt.cpu(), W.T.contiguous())
+    tol = grad_tol(gemm_mode)
     dx = torch.empty(M, K, device=DEV)
     ops.linear_bwd_input_t(dev(dy), Wt, dx)
-    assert rel_err(dx.cpu(), ref) < GEMM_TOL
+    assert rel_err(dx.cpu(), ref) < tol
     base = rnd(M, K, seed=5)
     dx2 = dev(base).clone()
     ops.linear_bwd_input_t(dev(dy), Wt, dx2, accumulate=True)
-    assert rel_err(dx2.cpu(), ref + base.double()) < GEMM_TOL
+    assert rel_err(dx2.cpu(), ref + base.double()) < tol
     gg = rnd(M, K, seed=6)
     dx3 = torch.empty(M, K, device=DEV)
     ops.linear_bwd_input_t(dev(dy), Wt, dx3, gelu_grad=dev(gg))
-    assert rel_err(dx3.cpu(), ref * gg.double()) < GEMM_TOL
+    assert rel_err(dx3.cpu(), ref * gg.double()) < tol
 
 
 def test_transpose_many_batched(ops):
@@ -165,7 +173,7 @@ def test_split_bf16_wide_dynamic_range(ops):
 
 def test_gemm_mode_switch(ops):
     prev = ops.get_gemm_mode()
-    assert prev in (ops.GEMM_F32, ops.GEMM_SPLIT_BF16)
+    assert prev == ops.GEMM_SPLIT_BF16_GRAD3                     # the default
     from vit_som_amd._lib import VsomError
     with pytest.raises(VsomError):
         ops.set_gemm_mode(7)
@@ -180,8 +188,8 @@ def test_linear_bwd_weight(ops, gemm_mode, M, N, K):
     dW_ref, db_ref = dy.double().T @ x.double(), dy.double().sum(0)
     dW, db = torch.empty(N, K, device=DEV), torch.empty(N, device=DEV)
     ops.linear_bwd_weight(dev(dy), dev(x), dW, db)
-    assert rel_err(dW.cpu(), dW_ref) < GEMM_TOL
-    assert rel_err(db.cpu(), db_ref) < GEMM_TOL
+    assert rel_err(dW.cpu(), dW_ref) < grad_tol(gemm_mode)
+    assert rel_err(db.cpu(), db_ref) < GEMM_TOL                  # the bias gradient is a plain fp32 column sum in every mode
     # deterministic: bitwise identical on a second run
     dW2, db2 = torch.empty(N, K, device=DEV), torch.empty(N, device=DEV)
     ops.linear_bwd_weight(dev(dy), dev(x), dW2, db2)

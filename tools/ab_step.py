@@ -12,6 +12,8 @@ from vit_som_amd.tuning import hooks
 def apply(key, v):
     if key == "attn_fused":
         ops.set_attention_fused(bool(int(v)))
+    elif key == "gemm_mode":                         # 0 f32 MFMA, 1 six products everywhere, 2 (default) three in the gradient GEMMs
+        ops.set_gemm_mode(int(v))
     else:
         hooks.set(**{key: (None if v == "None" else int(v))})
 

@@ -19,7 +19,8 @@ P64 = {k: (v.double() if v.is_floating_point() else v) for k, v in P.items()}
 torch.set_num_threads(os.cpu_count())
 total64, parts64, G64 = O.loss_and_grads(P64, x.double(), y, d, it, n_train, est)
 print(f"fp64 oracle loss {float(total64):.9f}")
-for mode, name in ((ops.GEMM_SPLIT_BF16, "split-bf16"), (ops.GEMM_F32, "f32 MFMA  ")):
+for mode, name in ((ops.GEMM_SPLIT_BF16_GRAD3, "split-bf16, gradient GEMMs 3 products (default)"), (ops.GEMM_SPLIT_BF16, "split-bf16, 6 products everywhere              "),
+                   (ops.GEMM_F32, "f32 MFMA                                       ")):
     ops.set_gemm_mode(mode)
     m = vit_som_amd.ViTSOM(copy.deepcopy(cfg), device="cuda")
     m.load_state_dict({k: v for k, v in P.items()}, strict=False)

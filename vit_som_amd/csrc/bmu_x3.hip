@@ -26,8 +26,6 @@ namespace vsom {
 constexpr float BMU_WINDOW = 2.0e-4f;      // 2 x (3 * 2^-16 = 4.6e-5, the split's worst case) = 9.2e-5, + as much again for the fp32
                                            // accumulation over L <= 49152 terms and the slab sums
 
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
-
 struct BmuP {
     const float* X; long ldx; const float* W;
     int B, K, L;
@@ -36,17 +34,6 @@ struct BmuP {
     float* xsq; float* wsq;             // [splits][B], [splits][K] partial squared norms
     unsigned x_bytes, w_bytes;
 };
-
-// 4 floats -> two planes of 4 bf16 (round to nearest even; v_cvt_pk_bf16_f32)
-__device__ __forceinline__ void x3_split(f32x4 v, uint2& p1, uint2& p2) {
-    const bf16x2_t a01 = {(__bf16)v[0], (__bf16)v[1]}, a23 = {(__bf16)v[2], (__bf16)v[3]};
-    const unsigned u01 = __builtin_bit_cast(unsigned, a01), u23 = __builtin_bit_cast(unsigned, a23);
-    const float r0 = v[0] - x6_float(u01 << 16), r1 = v[1] - x6_float(u01 & 0xffff0000u);
-    const float r2 = v[2] - x6_float(u23 << 16), r3 = v[3] - x6_float(u23 & 0xffff0000u);
-    const bf16x2_t b01 = {(__bf16)r0, (__bf16)r1}, b23 = {(__bf16)r2, (__bf16)r3};
-    p1.x = u01; p1.y = u23;
-    p2.x = __builtin_bit_cast(unsigned, b01); p2.y = __builtin_bit_cast(unsigned, b23);
-}
 
 // k-contiguous fp32 tile ROWS x 32 staged by NT threads: thread t loads float4 (row = p * (NT / 8) + t / 8, k = (t % 8) * 4)
 template <int ROWS, int NT> struct X3Stage { f32x4 v[ROWS / (NT / 8)]; };

@@ -55,6 +55,7 @@ struct GemmP {
     int n_major;                 // tile order inside a split: 1 = consecutive ids walk the m-tiles of one n-tile
     int a_vec, b_vec;            // 16-byte vector loads legal for A / B
     unsigned a_bytes, b_bytes;   // extent of A / B for the bounds-checked buffer loads (FAST path)
+    int products;                // split-bf16 engine: 6 (exact three-piece split; default when 0) or 3 (two-piece split)
 };
 
 template <int R_>

@@ -19,10 +19,13 @@ void set_error(const char* fmt, ...) {
 }
 const char* last_error() { return g_err; }
 
-// Arithmetic of the nn.Linear-shaped ("NT") GEMMs: VSOM_GEMM_SPLIT_BF16 (default) or VSOM_GEMM_F32.
-// The BMU distance GEMM (EPI_SLAB) always runs the exact-f32 engine.
-static std::atomic<int> g_gemm_mode{VSOM_GEMM_SPLIT_BF16};
+// Arithmetic of the nn.Linear-shaped GEMMs (include/vitsom_hip.h): VSOM_GEMM_F32, VSOM_GEMM_SPLIT_BF16 (exact three-piece
+// split, six products everywhere) or VSOM_GEMM_SPLIT_BF16_GRAD3 (default: the same forward; the weight- and input-gradient
+// GEMMs of the Linear layers on the two-piece split, three products).
+static std::atomic<int> g_gemm_mode{VSOM_GEMM_SPLIT_BF16_GRAD3};
 int gemm_mode() { return g_gemm_mode.load(std::memory_order_relaxed); }
+static bool split_engine() { return gemm_mode() != VSOM_GEMM_F32; }
+static int grad_products() { return gemm_mode() == VSOM_GEMM_SPLIT_BF16_GRAD3 ? 3 : 6; }
 
 // One tile configuration: 128 x 64 (4 waves, each 32 x 64 = two 32x32 accumulators).  Measured
 // against 128 x 128 on every GEMM shape of the step (and 4096^3): faster everywhere -- three
@@ -52,7 +55,7 @@ static int launch_t(GemmP& g, int splits, hipStream_t stream) {
     g.a_bytes = (unsigned)ab; g.b_bytes = (unsigned)bb;
     g.n_major = bb > ab;        // share the larger operand's panel between neighbouring workgroups
     if constexpr (!A_KC && !B_KC && (EPI == EPI_SLAB || EPI == EPI_ROWAXPY)) {
-        if (fast && gemm_mode() == VSOM_GEMM_SPLIT_BF16) {
+        if (fast && split_engine()) {
             if (BM == 64) VSOM_LAUNCH((gemm_x6_kernel<false, false, 1, 1, 2, 2, EPI>), grid, block, 0, stream, g);
             else VSOM_LAUNCH((gemm_x6_kernel<false, false, 1, 2, 4, 1, EPI>), grid, block, 0, stream, g);
             VSOM_LAUNCH_CHECK("gemm_x6_kernel");
@@ -66,13 +69,13 @@ static int launch_t(GemmP& g, int splits, hipStream_t stream) {
         }
     }
     if constexpr (A_KC && !B_KC && EPI == EPI_ROWAXPY) {
-        if (fast && gemm_mode() == VSOM_GEMM_SPLIT_BF16) {
+        if (fast && split_engine()) {
             VSOM_LAUNCH((gemm_x6_kernel<true, false, 1, 2, 4, 1, EPI>), grid, block, 0, stream, g);
             VSOM_LAUNCH_CHECK("gemm_x6_kernel");
         }
     }
     if constexpr (A_KC && B_KC && EPI != EPI_SLAB) {
-        if (fast && gemm_mode() == VSOM_GEMM_SPLIT_BF16) {
+        if (fast && split_engine()) {
             // 128 x 64 tiles; 64 x 64 only for problems of at most 64 rows.  (Rounds 1-2 chose between the two with a
             // "rounds of 256 workgroups" model fitted to each GEMM running ALONE, which sent about half of the step's
             // GEMMs to 64 x 64.  Inside the step two kernels share the chip nearly all the time (tools/timeline.py), and
@@ -82,6 +85,12 @@ static int launch_t(GemmP& g, int splits, hipStream_t stream) {
                 dim3 grid64(cdiv(g.M, 64) * cdiv(g.N, 64) * splits, 1, 1);
                 VSOM_LAUNCH((gemm_x6_kernel<true, true, 1, 1, 2, 2, EPI>), grid64, block, 0, stream, g);
                 VSOM_LAUNCH_CHECK("gemm_x6_kernel");
+            }
+            if constexpr (EPI == EPI_NONE || EPI == EPI_GELU_BWD) {          // the input-gradient GEMMs: three products on request
+                if (g.products == 3) {
+                    VSOM_LAUNCH((gemm_x6_kernel<true, true, 1, 2, 4, 1, EPI, 2>), grid, block, 0, stream, g);
+                    VSOM_LAUNCH_CHECK("gemm_x6_kernel");
+                }
             }
             VSOM_LAUNCH((gemm_x6_kernel<true, true, 1, 2, 4, 1, EPI>), grid, block, 0, stream, g);
             VSOM_LAUNCH_CHECK("gemm_x6_kernel");
@@ -290,7 +299,7 @@ int linear_bwd_weight_impl(const float* dY, long lddy, const float* X, long ldx,
     float* slab = static_cast<float*>(ws);
     const long a_last = a_seg ? (long)((M - 1) / a_seg) * a_stride + a_off + (M - 1) % a_seg : M - 1;
     const long ab = (a_last * lddy + N) * 4, bb = ((long)(M - 1) * ldx + K) * 4;
-    const bool tn_ok = plan.cfg != 0 && gemm_mode() == VSOM_GEMM_SPLIT_BF16 && aligned16(dY) && aligned16(X) &&
+    const bool tn_ok = plan.cfg != 0 && split_engine() && aligned16(dY) && aligned16(X) &&
                        lddy % 4 == 0 && ldx % 4 == 0 && ab < 0xFFFF0000L && bb < 0xFFFF0000L &&
                        (a_seg == 0 || (a_seg % 32 == 0 && M % a_seg == 0));
     if (tn_ok) {
@@ -301,10 +310,14 @@ int linear_bwd_weight_impl(const float* dY, long lddy, const float* X, long ldx,
         t.slab = slab; t.slab_stride = wlen + blen;
         t.slab_bias = db ? slab + wlen : nullptr; t.slab_bias_stride = wlen + blen;
         t.a_bytes = (unsigned)ab; t.b_bytes = (unsigned)bb;
-        if (plan.cfg == 1)
-            VSOM_LAUNCH((gemm_x6_tn_kernel<3, 1, 2, 2>), dim3((N / 192) * (K / 64) * splits), dim3(256), 0, stream, t);
-        else
-            VSOM_LAUNCH((gemm_x6_tn_kernel<3, 1, 1, 3>), dim3((N / 96) * (K / 96) * splits), dim3(192), 0, stream, t);
+        const bool x3 = grad_products() == 3;
+        if (plan.cfg == 1) {
+            if (x3) VSOM_LAUNCH((gemm_x6_tn_kernel<3, 1, 2, 2, 2>), dim3((N / 192) * (K / 64) * splits), dim3(256), 0, stream, t);
+            else VSOM_LAUNCH((gemm_x6_tn_kernel<3, 1, 2, 2, 3>), dim3((N / 192) * (K / 64) * splits), dim3(256), 0, stream, t);
+        } else {
+            if (x3) VSOM_LAUNCH((gemm_x6_tn_kernel<3, 1, 1, 3, 2>), dim3((N / 96) * (K / 96) * splits), dim3(192), 0, stream, t);
+            else VSOM_LAUNCH((gemm_x6_tn_kernel<3, 1, 1, 3, 3>), dim3((N / 96) * (K / 96) * splits), dim3(192), 0, stream, t);
+        }
         const int rc = hip_status(hipGetLastError(), "gemm_x6_tn_kernel");
         if (rc) return rc;
         return reduce_slabs2_internal(slab, wlen + blen, splits, dW, (long)N * K, db, wlen, db ? N : 0, stream);
@@ -403,6 +416,7 @@ int vsom_linear_bwd_input_t(const float* dY, long lddy, const float* Wt, float* 
     GemmP g = {};
     g.A = dY; g.lda = lddy; g.B = Wt; g.ldb = N; g.C = dX; g.ldc = lddx;
     g.M = M; g.N = K; g.K = N; g.alpha = 1.f; g.accumulate = accumulate;
+    g.products = grad_products();
     if (gelu_grad) {
         g.R = gelu_grad; g.ldr = K;
         return launch_gemm(true, true, EPI_GELU_BWD, g, 1, stream);
@@ -411,7 +425,8 @@ int vsom_linear_bwd_input_t(const float* dY, long lddy, const float* Wt, float* 
 }
 
 int vsom_set_gemm_mode(int mode) {
-    VSOM_REQUIRE(mode == VSOM_GEMM_F32 || mode == VSOM_GEMM_SPLIT_BF16, VSOM_EINVAL, "set_gemm_mode: unknown mode %d", mode);
+    VSOM_REQUIRE(mode == VSOM_GEMM_F32 || mode == VSOM_GEMM_SPLIT_BF16 || mode == VSOM_GEMM_SPLIT_BF16_GRAD3, VSOM_EINVAL,
+                 "set_gemm_mode: unknown mode %d", mode);
     g_gemm_mode.store(mode, std::memory_order_relaxed);
     return VSOM_OK;
 }

@@ -48,6 +48,20 @@ __device__ __forceinline__ void x6_split(f32x4 v, uint2& p1, uint2& p2, uint2& p
     p3.x = __builtin_amdgcn_perm(x6_bits(s[1]), x6_bits(s[0]), SEL); p3.y = __builtin_amdgcn_perm(x6_bits(s[3]), x6_bits(s[2]), SEL);
 }
 
+// 4 floats -> TWO planes of 4 bf16 (round to nearest even, v_cvt_pk_bf16_f32): a = a1 + a2 + r with |a2| <= 2^-9 |a|,
+// |r| <= 2^-17 |a|.  Three products a2 b1 + a1 b2 + a1 b1 then carry |error| <= 3 * 2^-16 |a||b| per term in the worst case
+// (random signs: ~2^-18 on a long sum): the BMU contraction (bmu_x3.hip) and the weight-gradient GEMM (gemm_x6_tn.h).
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+__device__ __forceinline__ void x3_split(f32x4 v, uint2& p1, uint2& p2) {
+    const bf16x2_t a01 = {(__bf16)v[0], (__bf16)v[1]}, a23 = {(__bf16)v[2], (__bf16)v[3]};
+    const unsigned u01 = __builtin_bit_cast(unsigned, a01), u23 = __builtin_bit_cast(unsigned, a23);
+    const float r0 = v[0] - x6_float(u01 << 16), r1 = v[1] - x6_float(u01 & 0xffff0000u);
+    const float r2 = v[2] - x6_float(u23 << 16), r3 = v[3] - x6_float(u23 & 0xffff0000u);
+    const bf16x2_t b01 = {(__bf16)r0, (__bf16)r1}, b23 = {(__bf16)r2, (__bf16)r3};
+    p1.x = u01; p1.y = u23;
+    p2.x = __builtin_bit_cast(unsigned, b01); p2.y = __builtin_bit_cast(unsigned, b23);
+}
+
 // LDS plane image: [row][64 B] = 32 bf16 of one k-tile, no padding; the 16-byte chunk c (8 consecutive k) of row R sits
 // at chunk position c ^ ((R >> 2) & 3).  With that XOR both access patterns are bank-conflict-free: the fragment reads
 // (ds_read_b128, lane = row: its 16-lane groups hit 16 different 16-byte slots of the 256-byte bank row) AND the staging
@@ -59,17 +73,17 @@ __device__ __forceinline__ int x6_chunk_off(int row, int chunk) { return row * X
 // byte offset of the 8-byte piece kq (4 consecutive k, kq = 0..7) of row `row`
 __device__ __forceinline__ int x6_piece_off(int row, int kq) { return x6_chunk_off(row, kq >> 1) + ((kq & 1) << 3); }
 
-template <int ROWS>
+template <int ROWS, int NPL = 3>
 __device__ __forceinline__ void x6_store(const StageRegs<ROWS>& s, char* planes, int t) {
     constexpr int PL = ROWS * X6_RS;
 #pragma unroll
     for (int p = 0; p < ROWS / 32; ++p) {
         uint2 p1, p2, p3;
-        x6_split(s.v[p], p1, p2, p3);
+        if constexpr (NPL == 3) x6_split(s.v[p], p1, p2, p3); else x3_split(s.v[p], p1, p2);
         char* dst = planes + x6_piece_off(p * 32 + (t >> 3), t & 7);
         *reinterpret_cast<uint2*>(dst) = p1;
         *reinterpret_cast<uint2*>(dst + PL) = p2;
-        *reinterpret_cast<uint2*>(dst + 2 * PL) = p3;
+        if constexpr (NPL == 3) *reinterpret_cast<uint2*>(dst + 2 * PL) = p3;
     }
 }
 
@@ -86,27 +100,29 @@ __device__ __forceinline__ void x6_load_ks(X6Blk& b, __amdgpu_buffer_rsrc_t rsrc
         b.v[i] = bload4(rsrc, (k < K && colbytes != OOB) ? row * ld4 + colbytes : OOB);
     }
 }
+template <int NPL = 3>
 __device__ __forceinline__ void x6_store_ks(const X6Blk& b, char* planes, int plane_bytes, int mq, int kg) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const f32x4 col = {b.v[0][e], b.v[1][e], b.v[2][e], b.v[3][e]};      // 4 consecutive k of column 4mq+e
         uint2 p1, p2, p3;
-        x6_split(col, p1, p2, p3);
+        if constexpr (NPL == 3) x6_split(col, p1, p2, p3); else x3_split(col, p1, p2);
         char* dst = planes + x6_piece_off(4 * mq + e, kg);
         *reinterpret_cast<uint2*>(dst) = p1;
         *reinterpret_cast<uint2*>(dst + plane_bytes) = p2;
-        *reinterpret_cast<uint2*>(dst + 2 * plane_bytes) = p3;
+        if constexpr (NPL == 3) *reinterpret_cast<uint2*>(dst + 2 * plane_bytes) = p3;
     }
 }
 
-template <bool A_KC, bool B_KC, int WM, int WN, int WAVES_M, int WAVES_N, int EPI>
+// NPL = 3: exact three-piece split, six products; NPL = 2: two-piece round-to-nearest split, three products (x3_split above)
+template <bool A_KC, bool B_KC, int WM, int WN, int WAVES_M, int WAVES_N, int EPI, int NPL = 3>
 __global__ __launch_bounds__(256) void gemm_x6_kernel(const GemmP g) {
     constexpr int BM = WAVES_M * WM * 32;
     constexpr int BN = WAVES_N * WN * 32;
     constexpr int PA = BM * X6_RS, PB = BN * X6_RS;
-    __shared__ __attribute__((aligned(16))) char lds[3 * (PA + PB)];
+    __shared__ __attribute__((aligned(16))) char lds[NPL * (PA + PB)];
     char* As = lds;
-    char* Bs = lds + 3 * PA;
+    char* Bs = lds + NPL * PA;
 
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
@@ -166,16 +182,16 @@ __global__ __launch_bounds__(256) void gemm_x6_kernel(const GemmP g) {
     };
     auto lstore = [&]() {
         if constexpr (A_KC) {
-            x6_store<BM>(sa, As, t);
+            x6_store<BM, NPL>(sa, As, t);
         } else if (has_a) {
             if (want_colsum) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) cs[e] += (ba.v[0][e] + ba.v[1][e]) + (ba.v[2][e] + ba.v[3][e]);
             }
-            x6_store_ks(ba, As, PA, mqa, kga);
+            x6_store_ks<NPL>(ba, As, PA, mqa, kga);
         }
-        if constexpr (B_KC) x6_store<BN>(sb, Bs, t);
-        else if (has_b) x6_store_ks(bb, Bs, PB, mqb, kgb);
+        if constexpr (B_KC) x6_store<BN, NPL>(sb, Bs, t);
+        else if (has_b) x6_store_ks<NPL>(bb, Bs, PB, mqb, kgb);
     };
 
     if (kt_begin < kt_end) {
@@ -187,26 +203,28 @@ __global__ __launch_bounds__(256) void gemm_x6_kernel(const GemmP g) {
     auto mfma_tile = [&]() {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 a[WM][3], b[WN][3];
+            bf16x8 a[WM][NPL], b[WN][NPL];
 #pragma unroll
             for (int i = 0; i < WM; ++i)
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl)
+                for (int pl = 0; pl < NPL; ++pl)
                     a[i][pl] = *reinterpret_cast<const bf16x8*>(As + pl * PA + x6_chunk_off(wm0 + i * 32 + r, 2 * ks + h));
 #pragma unroll
             for (int j = 0; j < WN; ++j)
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl)
+                for (int pl = 0; pl < NPL; ++pl)
                     b[j][pl] = *reinterpret_cast<const bf16x8*>(Bs + pl * PB + x6_chunk_off(wn0 + j * 32 + r, 2 * ks + h));
 #pragma unroll
             for (int i = 0; i < WM; ++i)
 #pragma unroll
                 for (int j = 0; j < WN; ++j) {
                     f32x16 c = acc[i][j];
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], c, 0, 0, 0);   // 2^-16 terms
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], c, 0, 0, 0);   // 2^-8 terms
+                    if constexpr (NPL == 3) {
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], c, 0, 0, 0);   // 2^-16 terms
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], c, 0, 0, 0);
+                    }
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], c, 0, 0, 0);   // 2^-8 (2^-9) terms
                     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], c, 0, 0, 0);
                     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], c, 0, 0, 0);   // leading term
                     acc[i][j] = c;

@@ -40,14 +40,17 @@ __device__ __forceinline__ s16x4 tn_trread(const char* p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
 }
 
-template <int WM, int WN, int WAVES_M, int WAVES_N>
+// NPL = 3: the exact three-piece split, six products (fp32-accurate: |error| < 2^-22 per product).  NPL = 2: the two-piece
+// round-to-nearest split, three products (|error| <= 3 * 2^-16 per product worst case, ~4e-6 relative on a weight gradient
+// summed over the token rows): half the matrix-core work, two LDS planes instead of three.
+template <int WM, int WN, int WAVES_M, int WAVES_N, int NPL>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void gemm_x6_tn_kernel(const TnP g) {
     constexpr int BM = WAVES_M * WM * 32, BN = WAVES_N * WN * 32, NT = WAVES_M * WAVES_N * 64;
     constexpr int SA = tn_stride(BM), SB = tn_stride(BN), PA = 32 * SA, PB = 32 * SB;
     constexpr int FA = (32 * BM / 4 + NT - 1) / NT, FB = (32 * BN / 4 + NT - 1) / NT;
-    static_assert(3 * (PA + PB) >= NT * FA * 16, "LDS too small for the bias partials");
-    __shared__ __attribute__((aligned(16))) char lds[3 * (PA + PB)];
-    char* As = lds; char* Bs = lds + 3 * PA;
+    static_assert(NPL * (PA + PB) >= NT * FA * 16, "LDS too small for the bias partials");
+    __shared__ __attribute__((aligned(16))) char lds[NPL * (PA + PB)];
+    char* As = lds; char* Bs = lds + NPL * PA;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm0 = (wave / WAVES_N) * WM * 32, wn0 = (wave % WAVES_N) * WN * 32;
     const int tiles_n = g.KI / BN, tiles_m = g.NO / BM, ntiles = tiles_m * tiles_n;
@@ -109,19 +112,19 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void gemm_x6_tn_kernel(cons
             if (la[i] < 0) continue;
             if (want_colsum) cs[i] += sa[i];
             uint2 p1, p2, p3;
-            x6_split(sa[i], p1, p2, p3);
+            if constexpr (NPL == 3) x6_split(sa[i], p1, p2, p3); else x3_split(sa[i], p1, p2);
             *reinterpret_cast<uint2*>(As + la[i]) = p1;
             *reinterpret_cast<uint2*>(As + PA + la[i]) = p2;
-            *reinterpret_cast<uint2*>(As + 2 * PA + la[i]) = p3;
+            if constexpr (NPL == 3) *reinterpret_cast<uint2*>(As + 2 * PA + la[i]) = p3;
         }
 #pragma unroll
         for (int i = 0; i < FB; ++i) {
             if (lb[i] < 0) continue;
             uint2 p1, p2, p3;
-            x6_split(sb[i], p1, p2, p3);
+            if constexpr (NPL == 3) x6_split(sb[i], p1, p2, p3); else x3_split(sb[i], p1, p2);
             *reinterpret_cast<uint2*>(Bs + lb[i]) = p1;
             *reinterpret_cast<uint2*>(Bs + PB + lb[i]) = p2;
-            *reinterpret_cast<uint2*>(Bs + 2 * PB + lb[i]) = p3;
+            if constexpr (NPL == 3) *reinterpret_cast<uint2*>(Bs + 2 * PB + lb[i]) = p3;
         }
     };
     // transposed fragment reads: lane l -> 16-lane group G = l >> 4 (columns 16 (G & 1) .., t rows 8 (G >> 1) ..),
@@ -142,24 +145,26 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void gemm_x6_tn_kernel(cons
     auto mfma_tile = [&]() {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 a[WM][3], b[WN][3];
+            bf16x8 a[WM][NPL], b[WN][NPL];
 #pragma unroll
             for (int i = 0; i < WM; ++i)
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) a[i][pl] = frag(As + pl * PA, fa[i], SA, ks);
+                for (int pl = 0; pl < NPL; ++pl) a[i][pl] = frag(As + pl * PA, fa[i], SA, ks);
 #pragma unroll
             for (int j = 0; j < WN; ++j)
 #pragma unroll
-                for (int pl = 0; pl < 3; ++pl) b[j][pl] = frag(Bs + pl * PB, fbo[j], SB, ks);
+                for (int pl = 0; pl < NPL; ++pl) b[j][pl] = frag(Bs + pl * PB, fbo[j], SB, ks);
 #pragma unroll
             for (int i = 0; i < WM; ++i)
 #pragma unroll
                 for (int j = 0; j < WN; ++j) {
                     f32x16 c = acc[i][j];
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], c, 0, 0, 0);   // 2^-16 terms
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], c, 0, 0, 0);   // 2^-8 terms
+                    if constexpr (NPL == 3) {
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][2], b[j][0], c, 0, 0, 0);   // 2^-16 terms
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][2], c, 0, 0, 0);
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][1], c, 0, 0, 0);
+                    }
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][1], b[j][0], c, 0, 0, 0);   // 2^-8 (2^-9) terms
                     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][1], c, 0, 0, 0);
                     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[j][0], c, 0, 0, 0);   // leading term
                     acc[i][j] = c;

@@ -763,7 +763,7 @@ class SOMLayer(_Base):
     def _distances_into(self, x2d, s: _Acts):
         if self._dist_mode == ops.DIST_COSINE:
             W = self.prototypes
-            if (ops.get_gemm_mode() == ops.GEMM_SPLIT_BF16 and W.shape[0] <= 2048 and W.shape[1] % 4 == 0
+            if (ops.get_gemm_mode() != ops.GEMM_F32 and W.shape[0] <= 2048 and W.shape[1] % 4 == 0
                     and x2d.stride(0) % 4 == 0 and x2d.data_ptr() % 16 == 0):
                 # norms + reduced-precision contraction + exact re-rank in one pass over X and W
                 ops.bmu_cosine_x3_fwd(x2d, W, s.dist, s.bmu, s.inx, s.inw, s.reranked)

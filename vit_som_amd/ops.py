@@ -160,7 +160,7 @@ def transpose_many(src_base, dst_base, table, max_rows, max_cols):
     return dst_base
 
 
-GEMM_F32, GEMM_SPLIT_BF16 = 0, 1
+GEMM_F32, GEMM_SPLIT_BF16, GEMM_SPLIT_BF16_GRAD3 = 0, 1, 2      # include/vitsom_hip.h: VSOM_GEMM_*
 
 
 def set_gemm_mode(mode: int):
