@@ -484,5 +484,6 @@ int reduce_slabs2_internal(const float* slabs, long stride, int nslabs, float* o
 int sum_partials(const float* part, int n, float* out, hipStream_t stream);
 int choose_splits(int tiles, int ktiles, int max_splits, bool prefer_xcd_multiple = false);
 int gemm_tile_m(bool a_kc, bool b_kc, int M);
+int gemm_grad_products();     // 3 in VSOM_GEMM_SPLIT_BF16_GRAD3 mode (gradient GEMMs on the two-piece split), else 6
 
 }  // namespace vsom

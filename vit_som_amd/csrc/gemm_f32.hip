@@ -25,7 +25,7 @@ const char* last_error() { return g_err; }
 static std::atomic<int> g_gemm_mode{VSOM_GEMM_SPLIT_BF16_GRAD3};
 int gemm_mode() { return g_gemm_mode.load(std::memory_order_relaxed); }
 static bool split_engine() { return gemm_mode() != VSOM_GEMM_F32; }
-static int grad_products() { return gemm_mode() == VSOM_GEMM_SPLIT_BF16_GRAD3 ? 3 : 6; }
+int gemm_grad_products() { return gemm_mode() == VSOM_GEMM_SPLIT_BF16_GRAD3 ? 3 : 6; }
 
 // One tile configuration: 128 x 64 (4 waves, each 32 x 64 = two 32x32 accumulators).  Measured
 // against 128 x 128 on every GEMM shape of the step (and 4096^3): faster everywhere -- three
@@ -57,6 +57,7 @@ static int launch_t(GemmP& g, int splits, hipStream_t stream) {
     if constexpr (!A_KC && !B_KC && (EPI == EPI_SLAB || EPI == EPI_ROWAXPY)) {
         if (fast && split_engine()) {
             if (BM == 64) VSOM_LAUNCH((gemm_x6_kernel<false, false, 1, 1, 2, 2, EPI>), grid, block, 0, stream, g);
+            else if (EPI == EPI_ROWAXPY && g.products == 3) VSOM_LAUNCH((gemm_x6_kernel<false, false, 1, 2, 4, 1, EPI, 2>), grid, block, 0, stream, g);
             else VSOM_LAUNCH((gemm_x6_kernel<false, false, 1, 2, 4, 1, EPI>), grid, block, 0, stream, g);
             VSOM_LAUNCH_CHECK("gemm_x6_kernel");
         }
@@ -70,7 +71,8 @@ static int launch_t(GemmP& g, int splits, hipStream_t stream) {
     }
     if constexpr (A_KC && !B_KC && EPI == EPI_ROWAXPY) {
         if (fast && split_engine()) {
-            VSOM_LAUNCH((gemm_x6_kernel<true, false, 1, 2, 4, 1, EPI>), grid, block, 0, stream, g);
+            if (g.products == 3) VSOM_LAUNCH((gemm_x6_kernel<true, false, 1, 2, 4, 1, EPI, 2>), grid, block, 0, stream, g);
+            else VSOM_LAUNCH((gemm_x6_kernel<true, false, 1, 2, 4, 1, EPI>), grid, block, 0, stream, g);
             VSOM_LAUNCH_CHECK("gemm_x6_kernel");
         }
     }
@@ -310,7 +312,7 @@ int linear_bwd_weight_impl(const float* dY, long lddy, const float* X, long ldx,
         t.slab = slab; t.slab_stride = wlen + blen;
         t.slab_bias = db ? slab + wlen : nullptr; t.slab_bias_stride = wlen + blen;
         t.a_bytes = (unsigned)ab; t.b_bytes = (unsigned)bb;
-        const bool x3 = grad_products() == 3;
+        const bool x3 = gemm_grad_products() == 3;
         if (plan.cfg == 1) {
             if (x3) VSOM_LAUNCH((gemm_x6_tn_kernel<3, 1, 2, 2, 2>), dim3((N / 192) * (K / 64) * splits), dim3(256), 0, stream, t);
             else VSOM_LAUNCH((gemm_x6_tn_kernel<3, 1, 2, 2, 3>), dim3((N / 192) * (K / 64) * splits), dim3(256), 0, stream, t);
@@ -416,7 +418,7 @@ int vsom_linear_bwd_input_t(const float* dY, long lddy, const float* Wt, float* 
     GemmP g = {};
     g.A = dY; g.lda = lddy; g.B = Wt; g.ldb = N; g.C = dX; g.ldc = lddx;
     g.M = M; g.N = K; g.K = N; g.alpha = 1.f; g.accumulate = accumulate;
-    g.products = grad_products();
+    g.products = gemm_grad_products();
     if (gelu_grad) {
         g.R = gelu_grad; g.ldr = K;
         return launch_gemm(true, true, EPI_GELU_BWD, g, 1, stream);

@@ -378,6 +378,7 @@ int vsom_som_bwd(const float* X, long ldx, const float* W, const float* coef, co
     g.A = coef; g.lda = K; g.B = X; g.ldb = ldx; g.C = gW; g.ldc = L;
     g.M = K; g.N = L; g.K = B;
     g.rowscale = col_dot; g.R = W; g.ldr = L; g.accumulate = 0;
+    g.products = gemm_grad_products();          // gradient GEMMs: three products in the default mode (gemm_f32.hip)
     int rc = launch_gemm(false, false, EPI_ROWAXPY, g, 1, stream);
     if (rc) return rc;
     // gX[B,L] (+)= coef[B,K] W[K,L] + row_dot[i] X[i,:]     (reduction over the prototypes)
@@ -385,6 +386,7 @@ int vsom_som_bwd(const float* X, long ldx, const float* W, const float* coef, co
     q.A = coef; q.lda = K; q.B = W; q.ldb = L; q.C = gX; q.ldc = ldgx;
     q.M = B; q.N = L; q.K = K;
     q.rowscale = row_dot; q.R = X; q.ldr = ldx; q.accumulate = accumulate_gx;
+    q.products = gemm_grad_products();
     return launch_gemm(true, false, EPI_ROWAXPY, q, 1, stream);
 }
 
