@@ -152,16 +152,25 @@ def bmu_roofline(ops, B, world, bmu_ms, bmu_calls):
     split = ops.get_gemm_mode() != ops.GEMM_F32
     # three bf16 products per fp32 product (two-piece split + exact re-rank) vs the exact-f32 MFMA engine
     peak = BF16_MFMA_PEAK_TFLOPS / 3.0 if split else F32_MFMA_PEAK_TFLOPS
+    from vit_som_amd.tuning import hooks
+    planes = split and hooks.bmu_planes and ops.bmu_planes_supported(B, K, L)
     traffic = None
     try:
-        t = json.load(open(os.path.join(ROOT, "profiles", "r02_bmu_hbm_traffic.json")))
-        if B == t["batch"] and world == 1 and split:
+        t = json.load(open(os.path.join(ROOT, "profiles", "r03_bmu_hbm_traffic.json")))
+        if B == t["batch"] and world == 1 and split and ("planes" in t["kernel"]) == planes:
             traffic = t["read_bytes"] + t["write_bytes"]
     except (OSError, KeyError, ValueError):
         pass
-    return {"kernel": ("bmu_x3_kernel<2,3,4,2> (BMU distance pass: X[B,L] . W[K,L]^T on bf16 MFMA from a two-piece split, three "
-                       "products, row norms fused in, split over L; exact fp64 re-rank in bmu_x3_finalize_kernel)") if split
-                      else "gemm_f32_kernel<true,true,1,2,4,1,6,true> (BMU distance pass on f32 MFMA)",
+    if planes:
+        kernel = ("bmu_x3_planes_kernel (BMU distance pass: X[B,L] . W[K,L]^T on bf16 MFMA, three products of a two-piece split; "
+                  "operands pre-split into plane images by planes_kernel -- X ~12 us and W ~33 us per step, separate launches NOT "
+                  "in this kernel's time -- fed by LDS-DMA; split over L; exact fp64 re-rank in bmu_x3_finalize_kernel)")
+    elif split:
+        kernel = ("bmu_x3_kernel<2,3,4,2> (BMU distance pass: X[B,L] . W[K,L]^T on bf16 MFMA from a two-piece split, three "
+                  "products, row norms fused in, split over L; exact fp64 re-rank in bmu_x3_finalize_kernel)")
+    else:
+        kernel = "gemm_f32_kernel<true,true,1,2,4,1,6,true> (BMU distance pass on f32 MFMA)"
+    return {"kernel": kernel,
             "bound": "mfma", "achieved": round(flops / t_s / 1e12, 3), "peak": round(peak, 1), "unit": "TFLOP/s",
             "frac": round(flops / t_s / 1e12 / peak, 4),
             "peak_basis": "dense bf16 MFMA 2500 TF / 3 products per fp32 product" if split else "dense f32 MFMA",

@@ -323,6 +323,30 @@ int vsom_bmu_cosine_x3_finalize(const float* X, long ldx, const float* W, const 
                                 int64_t* bmu, float* inv_nx, float* inv_nw, int* reranked, int B, int K, int L,
                                 vsom_stream_t stream);
 
+/* The same pass on PRE-SPLIT operands ("plane images"): the two-piece bf16 split is taken out of the contraction and done
+   once per operand -- for the prototypes by the optimizer step that rewrites them anyway (vsom_adamw_step_planes), for the
+   samples by vsom_bmu_planes_from -- so that the contraction is LDS-DMA -> ds_read -> MFMA with no VALU in its loop.
+   A plane buffer (vsom_bmu_planes_bytes(R, L) bytes, 16-byte aligned) holds, for an operand [R, L]: the fragment image
+   (per 16-deep k step and 32-row block the two planes as 1 KB MFMA fragments, rows >= R and k >= L zero) followed by the
+   rows' squared-norm partials.  The caller owns validity: a plane buffer describes the operand as it was when written.
+   Covered shapes: vsom_bmu_cosine_x3_planes_supported (B >= 192, L % 8 == 0, K <= 2048, images < 2 GB); slabs, and
+   therefore dist / bmu, are those of vsom_bmu_cosine_x3_dots bit for bit (norms: last-bit differences).
+   Same reference lines as above (som_layer.py:119-122, 83-89); the AdamW variant replaces vit_som.py:146-151. */
+size_t vsom_bmu_planes_bytes(int R, int L);
+int vsom_bmu_planes_from(const float* src, long ld, int R, int L, void* planes, size_t planes_bytes, vsom_stream_t stream);
+/* vsom_adamw_step over the arena of n elements (same arguments, bitwise the same update) that also writes the plane
+   buffer of the [R, L] parameter at element offset slice_off (a multiple of 256) from its UPDATED values. */
+int vsom_adamw_step_planes(float* p, const float* g, float* m, float* v, const float* wd_per_chunk, long n, float lr,
+                           float beta1, float beta2, float eps, int step, float grad_scale, int adamw, long slice_off,
+                           int R, int L, void* planes, size_t planes_bytes, vsom_stream_t stream);
+int vsom_bmu_cosine_x3_planes_supported(int B, int K, int L);
+size_t vsom_bmu_cosine_x3_planes_workspace_bytes(int B, int K, int L);
+int vsom_bmu_cosine_x3_planes_dots(const void* xplanes, const void* wplanes, int B, int K, int L, void* ws, size_t ws_bytes,
+                                   vsom_stream_t stream);
+int vsom_bmu_cosine_x3_planes_finalize(const float* X, long ldx, const float* W, const void* xplanes, const void* wplanes,
+                                       const void* ws, size_t ws_bytes, float* dist, int64_t* bmu, float* inv_nx, float* inv_nw,
+                                       int* reranked, int B, int K, int L, vsom_stream_t stream);
+
 /* ------------------------------------------------------------------ small utilities */
 int vsom_fill(float* p, long n, float value, vsom_stream_t stream);
 /* out[0] = ca * a[0] + cb * b[0]: the step's total loss from its two device-side sums (vit_som.py:93,98); `counter`

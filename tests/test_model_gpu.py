@@ -664,7 +664,7 @@ def test_loss_parts_are_plain_tensors_with_a_lifetime():
     assert {k: float(first[k]) for k in ("total", "main", "som")} == v0 and float(l0) == v0["total"]
 
 
-@pytest.mark.parametrize("mode,B", [("cluster", 64), ("cls", 24)])
+@pytest.mark.parametrize("mode,B", [("cluster", 64), ("cls", 24), ("cluster", 192)])      # 192: BMU pass on plane images
 def test_launch_tape_replays_the_step_bit_for_bit(mode, B):
     """The launch tape (vsom_tape_*): after two host-driven steps the third is recorded while it runs and every later
     step re-issues those launches from C.  8 steps through train_step_fused AND through training_step().backward() (with a
@@ -711,3 +711,86 @@ def test_launch_tape_replays_the_step_bit_for_bit(mode, B):
     assert nops[0] > 20 and nops[1] >= 1 and nops[2] == 4 and nops[3] > 60, nops
     assert o0 == o1 and it0 == it1 == 8            # the device-side iteration buffer advanced once per training step, replayed or not
     assert torch.equal(g0, g1) and torch.equal(p0, p1)
+
+
+def test_bmu_plane_images_follow_the_prototypes():
+    """The cosine BMU pass on pre-split plane images (B >= 192): the prototypes' image is rewritten by the optimizer step,
+    the step results equal the in-loop-split path's (losses to fp32 rounding of the row norms, same BMUs), and every other
+    change of the prototypes -- an in-place torch op, load_state_dict, invalidate_planes() after a raw write -- is seen."""
+    import vit_som_amd
+    from oracle.gen_golden import make_config
+    from vit_som_amd import ops
+    from vit_som_amd.tuning import hooks
+    B = 192
+    cfg = make_config(3, 32, 4, 192, 3, 3, 96, 2, (8, 8), 0, B, gamma=0.02, Tmax=4.0, Tmin=0.1)
+    g = torch.Generator().manual_seed(5)
+    xs = [torch.randn(B, 3, 32, 32, generator=g).to(DEV) for _ in range(6)]
+    y = torch.zeros(B, dtype=torch.int64, device=DEV)
+
+    def run(planes_on, adamw_planes=False):
+        hooks.set(bmu_planes=planes_on, adamw_planes=adamw_planes)
+        try:
+            torch.manual_seed(0)
+            m = vit_som_amd.ViTSOM(copy.deepcopy(cfg), device=DEV)
+            m.set_schedule(4000, 400)
+            m._it = 40
+            (opt,), _ = m.configure_optimizers()
+            out = []
+            for i in range(6):
+                loss = m.train_step_fused(xs[i], y)
+                out.append((float(loss), m._ctx[2].bmu.clone(), m._ctx[2].dist.clone()))
+                opt.step()
+            return m, out
+        finally:
+            hooks.reset()
+
+    m0, o0 = run(False)
+    m1, o1 = run(True)                                               # default: re-split on the SOM stream every training step
+    m2, o2 = run(True, adamw_planes=True)                            # the optimizer writes the image
+    som = m1.som_layer
+    assert m0.som_layer._wplanes is None and som._wplanes is not None and som._planes_used
+    assert som._wplanes_stamp != som._w_stamp()                      # the optimizer step went past the image ...
+    som2 = m2.som_layer
+    assert som2._wplanes_stamp == som2._w_stamp()                    # ... here it left it current,
+    fresh = ops.bmu_planes_alloc(*som2.prototypes.shape, DEV)
+    ops.bmu_planes_from(som2.prototypes.detach(), fresh)
+    assert torch.equal(fresh, som2._wplanes)                         # and it is the image of the updated prototypes
+    assert torch.equal(m1.arena.params, m2.arena.params)             # same arithmetic either way
+    assert [l for l, _, _ in o1] == [l for l, _, _ in o2]
+    for i, ((l0, b0, d0), (l1, b1, d1)) in enumerate(zip(o0, o1)):
+        assert abs(l0 - l1) <= 2e-6 * abs(l0), (i, l0, l1)
+        assert float((d0 - d1).abs().max()) < 1e-6, i
+        assert int((b0 != b1).sum()) <= 1, i                         # a last-bit norm difference may flip an exact-to-fp32 tie
+
+    x = xs[0]
+    with torch.no_grad():
+        fwd = m1.forward(x)
+    # in-place torch op
+    with torch.no_grad():
+        som.prototypes[5].copy_(som.prototypes[9])
+        som.prototypes.mul_(1.5)
+    ref_d = 1 - torch.nn.functional.normalize(m1._som_input(m1.vit._acts[B]).double(), dim=1) @ \
+        torch.nn.functional.normalize(som.prototypes.detach().double(), dim=1).T
+    s = som._buffers_for(B, x.device)
+    som._distances_into(m1._som_input(m1.vit._acts[B]), s)
+    assert som._wplanes_stamp == som._w_stamp()
+    assert float((s.dist.double() - ref_d).abs().max()) < 1e-5
+    assert torch.equal(s.bmu, s.dist.argmin(1))
+    tie = s.bmu.cpu()
+    assert not bool((tie == 9).any())                                # rows 5 and 9 are identical now: the lower index wins
+    # raw write + invalidate_planes()
+    som.prototypes.data[7] = som.prototypes.data[2]                  # bypasses the version counter of the Parameter
+    som.invalidate_planes()
+    som._distances_into(m1._som_input(m1.vit._acts[B]), s)
+    assert not bool((s.bmu == 7).any())
+    # load_state_dict
+    sd = {k: v.clone() for k, v in m0.state_dict().items()}
+    m1.load_state_dict(sd)
+    assert som._wplanes_stamp != som._w_stamp()
+    with torch.no_grad():
+        out1 = m1.forward(x)
+        out0 = m0.forward(x)
+    assert len(fwd) == len(out1)
+    for a0, a1 in zip(out0, out1):
+        if torch.is_tensor(a0) and a0.is_floating_point():
+            assert float((a0 - a1).abs().max()) < 1e-6

@@ -423,6 +423,84 @@ def test_bmu_cosine_x3_more_candidates_than_one_chunk(ops):
         assert int(bmu[i]) != 650
 
 
+@pytest.mark.parametrize("B,K,L", [(512, 1600, 12288), (256, 576, 12288), (200, 70, 72), (192, 33, 8), (320, 1601, 1000)])
+def test_bmu_cosine_x3_planes_equal_the_in_loop_split(ops, B, K, L):
+    """The pre-split ("planes") form of the cosine BMU pass: partial-dot slabs bit-identical to the in-loop-split kernel's
+    (same products, same order, same reduction split), norms to the last bits, hence distances to ~1e-7 and the same BMUs;
+    ragged shapes (rows and prototypes that do not fill 32-row blocks, L that does not fill a 32-deep k-tile)."""
+    if ops.get_gemm_mode() == ops.GEMM_F32:
+        pytest.skip("the cosine BMU pass runs on the exact-f32 engine in this mode")
+    assert ops.bmu_planes_supported(B, K, L)
+    xd = dev(rnd(B, L + 8, seed=3))[:, :L]                                 # a row stride that is not L
+    x = xd.cpu()
+    W = F.normalize(torch.rand(K, L, generator=torch.Generator().manual_seed(4)), dim=1)
+    Wd = dev(W)
+    lib = ops.lib
+    from vit_som_amd._lib import ptr, stream
+    # slabs, both ways
+    nb0, nb1 = lib.vsom_bmu_cosine_x3_workspace_bytes(B, K, L), lib.vsom_bmu_cosine_x3_planes_workspace_bytes(B, K, L)
+    ws0, ws1 = torch.zeros(nb0, dtype=torch.uint8, device=DEV), torch.zeros(nb1, dtype=torch.uint8, device=DEV)
+    xp, wp = ops.bmu_planes_alloc(B, L, DEV), ops.bmu_planes_alloc(K, L, DEV)
+    ops.bmu_planes_from(xd, xp); ops.bmu_planes_from(Wd, wp)
+    assert lib.vsom_bmu_cosine_x3_dots(ptr(xd), xd.stride(0), ptr(Wd), B, K, L, ptr(ws0), nb0, stream()) == 0
+    assert lib.vsom_bmu_cosine_x3_planes_dots(ptr(xp), ptr(wp), B, K, L, ptr(ws1), nb1, stream()) == 0
+    nslab = (nb1 - 16) // 4
+    assert torch.equal(ws0.view(torch.float32)[:nslab], ws1.view(torch.float32)[:nslab])
+    # whole pass
+    out = []
+    for planes in (False, True):
+        inx, inw = torch.empty(B, device=DEV), torch.empty(K, device=DEV)
+        dist, bmu = torch.empty(B, K, device=DEV), torch.empty(B, dtype=torch.int64, device=DEV)
+        cnt = torch.zeros(1, dtype=torch.int32, device=DEV)
+        if planes:
+            ops.bmu_cosine_x3_planes_fwd(xd, Wd, xp, wp, dist, bmu, inx, inw, cnt)
+        else:
+            ops.bmu_cosine_x3_fwd(xd, Wd, dist, bmu, inx, inw, cnt)
+        out.append((dist.cpu(), bmu.cpu(), inx.cpu(), inw.cpu(), int(cnt)))
+    (d0, b0, ix0, iw0, c0), (d1, b1, ix1, iw1, c1) = out
+    assert torch.allclose(ix0, ix1, rtol=1e-6) and torch.allclose(iw0, iw1, rtol=1e-6)
+    assert float((d0 - d1).abs().max()) < 5e-7
+    assert torch.equal(b1, d1.argmin(1))
+    d64 = 1 - F.normalize(x.double(), dim=1) @ F.normalize(W.double(), dim=1).T
+    assert float((d1.double() - d64).abs().max()) < 1e-5
+    ok, nmis = bmu_policy_ok(b1, d64)
+    assert ok, f"{nmis} BMU mismatches outside near-ties"
+    same = int((b0 == b1).sum())
+    print(f"bmu planes B={B} K={K} L={L}: slabs bit-identical, max |dist planes - dist in-loop| {float((d0 - d1).abs().max()):.1e}, "
+          f"same BMU on {same}/{B} rows, re-ranked {c0} / {c1}")
+    assert same >= B - 1
+
+
+def test_adamw_step_planes_is_the_flat_step_plus_the_split(ops):
+    """vsom_adamw_step_planes: parameters and moments bitwise those of the flat kernel over the whole arena, and the plane
+    buffer of the slice bytewise the one vsom_bmu_planes_from writes from the UPDATED values."""
+    R, L = 70, 136                                   # 9520 elements: the slice ends inside a 256-chunk (padding follows)
+    lead, tail = 256 * 3, 256 * 2
+    padded = (R * L + 255) // 256 * 256
+    n = lead + padded + tail
+    g0 = torch.Generator().manual_seed(0)
+    p, gr = torch.randn(n, generator=g0), torch.randn(n, generator=g0)
+    p[lead + R * L:lead + padded] = 0; gr[lead + R * L:lead + padded] = 0
+    wd = torch.rand(n // 256, generator=g0) * 0.05
+    pa, pb = dev(p).clone(), dev(p).clone()
+    ma, va, mb, vb = (torch.zeros(n, device=DEV) for _ in range(4))
+    planes, ref = ops.bmu_planes_alloc(R, L, DEV), ops.bmu_planes_alloc(R, L, DEV)
+    planes.zero_(); ref.zero_()
+    for step in range(1, 4):
+        for adamw in (True, False):
+            ops.adamw_step(pa, dev(gr), ma, va, dev(wd), 3e-3, 0.9, 0.999, 1e-8, step, grad_scale=0.5, adamw=adamw)
+            ops.adamw_step(pb, dev(gr), mb, vb, dev(wd), 3e-3, 0.9, 0.999, 1e-8, step, grad_scale=0.5, adamw=adamw,
+                           planes=(lead, R, L, planes))
+            assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb), (step, adamw)
+            ops.bmu_planes_from(pb[lead:lead + R * L].view(R, L), ref)
+            assert torch.equal(planes, ref), (step, adamw)
+    # argument checks: a slice that is not chunk-aligned, a short plane buffer
+    with pytest.raises(Exception):
+        ops.adamw_step(pb, dev(gr), mb, vb, dev(wd), 3e-3, 0.9, 0.999, 1e-8, 1, planes=(lead + 4, R, L, planes))
+    with pytest.raises(Exception):
+        ops.adamw_step(pb, dev(gr), mb, vb, dev(wd), 3e-3, 0.9, 0.999, 1e-8, 1, planes=(lead, R, L, planes[:1024]))
+
+
 def test_bmu_exact_ties_pick_lowest_index(ops):
     B, K, L = 8, 40, 64
     x = rnd(B, L, seed=1)

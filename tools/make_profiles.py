@@ -40,7 +40,7 @@ for k in fetch:
     wr = statistics.median(write.get(k, {}).get("WRITE_SIZE", {0: 0.0}).values()) * 1024
     trows.append((len(fetch[k]["FETCH_SIZE"]) * (rd + wr), k, len(fetch[k]["FETCH_SIZE"]), rd, wr))
 trows.sort(reverse=True)
-bmu = [t for t in trows if "bmu_x3_kernel" in t[1]]
+bmu = [t for t in trows if "bmu_x3_planes_kernel" in t[1]] or [t for t in trows if "bmu_x3_kernel" in t[1]]
 adam = [t for t in trows if "adamw_kernel" in t[1]]
 with open(f"{out}/{tag}_bench_n1_pmc_hbm_traffic.txt", "w") as f:
     f.write("# rocprofv3 --kernel-trace --pmc FETCH_SIZE  and  rocprofv3 --kernel-trace --pmc WRITE_SIZE  (two separate passes)\n"
@@ -52,13 +52,13 @@ with open(f"{out}/{tag}_bench_n1_pmc_hbm_traffic.txt", "w") as f:
         f.write(f"# Calibration inside this run: adamw_kernel reads 4 x 100.4 MB = 401.6 MB algorithmic -> {adam[0][3]/1e6:.1f} MB measured; writes 3 x 100.4 = 301.2 MB -> {adam[0][4]/1e6:.1f} MB.\n")
     if bmu:
         alg = bench["roofline"]["algorithmic_bytes"]
-        f.write(f"# BMU distance pass = bmu_x3_kernel: algorithmic {alg/1e6:.1f} MB (X 25.2 + W 78.6 + dist 3.3); measured {bmu[0][3]/1e6:.1f} MB read + {bmu[0][4]/1e6:.1f} MB written "
+        f.write(f"# BMU distance pass, contraction kernel ({bmu[0][1].split('(')[0]}): algorithmic {alg/1e6:.1f} MB (X 25.2 + W 78.6 + dist 3.3); measured {bmu[0][3]/1e6:.1f} MB read + {bmu[0][4]/1e6:.1f} MB written "
                 f"(slabs of the L split + norm partials) = {(bmu[0][3]+bmu[0][4])/1e6:.1f} MB per launch = {(bmu[0][3]+bmu[0][4])/alg:.2f} x algorithmic.\n")
     f.write("\n")
     for _, k, n, rd, wr in trows[:40]:
         f.write(f"{k[:96]:96s} launches {n:4d}  read {rd/1e6:8.1f} MB  write {wr/1e6:8.1f} MB\n")
 if bmu:
-    json.dump({"kernel": "bmu_x3_kernel", "batch": 512, "read_bytes": round(bmu[0][3]), "write_bytes": round(bmu[0][4]),
+    json.dump({"kernel": bmu[0][1].split("(")[0].replace("vsom::", "").replace("void ", ""), "batch": 512, "read_bytes": round(bmu[0][3]), "write_bytes": round(bmu[0][4]),
                "source": f"profiles/{tag}_bench_n1_pmc_hbm_traffic.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py; read = 2 x FETCH_SIZE x 1024)"},
               open(f"{out}/{tag}_bmu_hbm_traffic.json", "w"), indent=1)
 

@@ -80,6 +80,15 @@ SIGNATURES = {
     "vsom_bmu_cosine_x3_dots": (C.c_int, [c_fp, C.c_long, c_fp, C.c_int, C.c_int, C.c_int, c_fp, C.c_size_t, c_stream]),
     "vsom_bmu_cosine_x3_finalize": (C.c_int, [c_fp, C.c_long, c_fp, c_fp, C.c_size_t, c_fp, c_fp, c_fp, c_fp, c_fp, C.c_int,
                                               C.c_int, C.c_int, c_stream]),
+    "vsom_bmu_planes_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "vsom_bmu_planes_from": (C.c_int, [c_fp, C.c_long, C.c_int, C.c_int, c_fp, C.c_size_t, c_stream]),
+    "vsom_adamw_step_planes": (C.c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, C.c_long, C.c_float, C.c_float, C.c_float, C.c_float,
+                                         C.c_int, C.c_float, C.c_int, C.c_long, C.c_int, C.c_int, c_fp, C.c_size_t, c_stream]),
+    "vsom_bmu_cosine_x3_planes_supported": (C.c_int, [C.c_int, C.c_int, C.c_int]),
+    "vsom_bmu_cosine_x3_planes_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "vsom_bmu_cosine_x3_planes_dots": (C.c_int, [c_fp, c_fp, C.c_int, C.c_int, C.c_int, c_fp, C.c_size_t, c_stream]),
+    "vsom_bmu_cosine_x3_planes_finalize": (C.c_int, [c_fp, C.c_long, c_fp, c_fp, c_fp, c_fp, C.c_size_t, c_fp, c_fp, c_fp, c_fp,
+                                                     c_fp, C.c_int, C.c_int, C.c_int, c_stream]),
     "vsom_som_neigh_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "vsom_som_neigh_loss": (C.c_int, [c_fp, c_fp, c_fp, C.c_float, c_fp, c_fp, C.c_float, c_fp, c_fp, c_fp, c_fp,
                                       c_fp, C.c_int, C.c_int, C.c_int, c_fp, C.c_size_t, c_stream]),

@@ -1,5 +1,5 @@
 // Patch embedding, losses, fused AdamW, small utilities.
-#include "gemm_f32.h"
+#include "adamw.h"
 
 namespace vsom {
 
@@ -152,26 +152,14 @@ __global__ __launch_bounds__(256) void ce_ls_kernel(const float* __restrict__ lo
 // ------------------------------------------------------------------ AdamW over a flat arena
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                     float* __restrict__ m, float* __restrict__ v,
-                                                    const float* __restrict__ wd_chunk, long n4, float lr,
-                                                    float b1, float b2, float eps, float step_size,
-                                                    float inv_bc2_sqrt, float gscale, int adamw) {
+                                                    const float* __restrict__ wd_chunk, long n4, const AdamwC c) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
         const float wd = wd_chunk[i >> 6];              // 64 float4 = 256 elements per chunk
         f32x4 pp = reinterpret_cast<f32x4*>(p)[i];
         const f32x4 gg = reinterpret_cast<const f32x4*>(g)[i];
         f32x4 mm = reinterpret_cast<f32x4*>(m)[i];
         f32x4 vv = reinterpret_cast<f32x4*>(v)[i];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float gr = gg[e] * gscale;
-            float pe = pp[e];
-            if (adamw) pe *= (1.f - lr * wd); else gr = fmaf(wd, pe, gr);
-            const float me = mm[e] + (gr - mm[e]) * (1.f - b1);          // lerp_, torch/optim/adam.py
-            const float ve = fmaf(vv[e], b2, (1.f - b2) * gr * gr);
-            const float denom = sqrtf(ve) * inv_bc2_sqrt + eps;
-            pp[e] = pe - step_size * (me / denom);
-            mm[e] = me; vv[e] = ve;
-        }
+        adamw_update(pp, gg, mm, vv, wd, c);
         reinterpret_cast<f32x4*>(p)[i] = pp;
         reinterpret_cast<f32x4*>(m)[i] = mm;
         reinterpret_cast<f32x4*>(v)[i] = vv;
@@ -406,13 +394,9 @@ int vsom_adamw_step(float* p, const float* g, float* m, float* v, const float* w
     VSOM_REQUIRE(n > 0 && n % 256 == 0, VSOM_EINVAL, "adamw_step: n=%ld must be a positive multiple of 256", n);
     VSOM_REQUIRE(step >= 1, VSOM_EINVAL, "adamw_step: step must be >= 1");
     VSOM_REQUIRE(aligned16(p) && aligned16(g) && aligned16(m) && aligned16(v), VSOM_EALIGN, "adamw_step: 16-byte alignment required");
-    const double bc1 = 1.0 - pow((double)beta1, step);
-    const double bc2 = 1.0 - pow((double)beta2, step);
-    const float step_size = (float)((double)lr / bc1);
-    const float inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
     const long n4 = n / 4;
     VSOM_LAUNCH(adamw_kernel, dim3(grid_for(n4, 256, 8192)), dim3(256), 0, stream, p, g, m, v, wd_per_chunk, n4,
-                       lr, beta1, beta2, eps, step_size, inv_bc2_sqrt, grad_scale, adamw);
+                adamw_constants(lr, beta1, beta2, eps, step, grad_scale, adamw));
     VSOM_LAUNCH_CHECK("adamw_kernel");
 }
 

@@ -718,6 +718,59 @@ class SOMLayer(_Base):
         self._world_size = 1
         self._n_train: Optional[int] = None
         self._bufs: Dict[int, _Acts] = {}
+        # pre-split plane image of the prototypes for the BMU contraction (ops.bmu_planes_*): valid while its stamp
+        # equals _w_stamp().  FusedAdamW rewrites it in the pass that updates the prototypes; anything else that
+        # changes them is seen through torch's version counter, the storage address or _raw_updates.
+        self._wplanes: Optional[torch.Tensor] = None
+        self._wplanes_stamp = None
+        self._raw_updates = 0           # updates of the prototypes that bypass torch (raw-pointer kernels)
+        self._planes_used = False       # a forward took the planes path: the optimizer keeps the image current
+
+    # ---- plane image of the prototypes ---------------------------------------------------
+    def _w_stamp(self):
+        W = self.prototypes
+        return (W.data_ptr(), W._version, self._raw_updates, tuple(W.shape))
+
+    def invalidate_planes(self):
+        """Call after changing the prototypes behind torch's back (writes through ``.data`` or a raw pointer)."""
+        self._wplanes_stamp = None
+
+    def _planes_shape_ok(self, B: int) -> bool:
+        W = self.prototypes
+        return bool(hooks.bmu_planes and self._dist_mode == ops.DIST_COSINE and W.is_cuda and ops.get_gemm_mode() != ops.GEMM_F32
+                    and ops.bmu_planes_supported(B, W.shape[0], W.shape[1]))
+
+    def _w_planes(self) -> torch.Tensor:
+        """The prototypes' plane buffer, re-split here if it does not describe them any more."""
+        W = self.prototypes
+        if self._wplanes is None or self._wplanes.device != W.device or self._wplanes.numel() != ops.lib.vsom_bmu_planes_bytes(*W.shape):
+            self._wplanes = ops.bmu_planes_alloc(W.shape[0], W.shape[1], W.device)
+            self._wplanes_stamp = None
+        if self._wplanes_stamp != self._w_stamp():
+            ops.bmu_planes_from(W.detach(), self._wplanes)
+            self._wplanes_stamp = self._w_stamp()
+        return self._wplanes
+
+    def _w_planes_async(self, side_stream, force: bool):
+        """Bring the prototypes' image up to date on `side_stream`, behind everything the launch stream holds so far
+        (the optimizer step that wrote the prototypes, the last contraction that read the image) -- when it is stale,
+        or always with `force` (a recorded training step must contain the launch whatever the state it was recorded
+        in).  Returns the event the consumer has to wait for, or None when nothing was launched."""
+        W = self.prototypes
+        if self._wplanes is None or self._wplanes.device != W.device or self._wplanes.numel() != ops.lib.vsom_bmu_planes_bytes(*W.shape):
+            self._wplanes = ops.bmu_planes_alloc(W.shape[0], W.shape[1], W.device)
+            self._wplanes_stamp = None
+        if not force and self._wplanes_stamp == self._w_stamp():
+            return None
+        Event.pooled().record().wait(side_stream)
+        with on_stream(side_stream):
+            ops.bmu_planes_from(W.detach(), self._wplanes)
+        self._wplanes_stamp = self._w_stamp()
+        return Event.pooled().record(side_stream)
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        super()._load_from_state_dict(*args, **kwargs)
+        self.invalidate_planes()
 
     def create_grid_positions(self):                                   # som_layer.py:60-81
         if self.topology == "square":
@@ -766,7 +819,16 @@ class SOMLayer(_Base):
             if (ops.get_gemm_mode() != ops.GEMM_F32 and W.shape[0] <= 2048 and W.shape[1] % 4 == 0
                     and x2d.stride(0) % 4 == 0 and x2d.data_ptr() % 16 == 0):
                 # norms + reduced-precision contraction + exact re-rank in one pass over X and W
-                ops.bmu_cosine_x3_fwd(x2d, W, s.dist, s.bmu, s.inx, s.inw, s.reranked)
+                if self._planes_shape_ok(x2d.shape[0]):
+                    # ... on pre-split operands: the prototypes' image is kept by the optimizer, the samples' written here
+                    self._planes_used = True
+                    if getattr(s, "xplanes", None) is None:
+                        s.xplanes = ops.bmu_planes_alloc(x2d.shape[0], x2d.shape[1], x2d.device)
+                    wplanes = self._w_planes()
+                    ops.bmu_planes_from(x2d, s.xplanes)
+                    ops.bmu_cosine_x3_planes_fwd(x2d, W, s.xplanes, wplanes, s.dist, s.bmu, s.inx, s.inw, s.reranked)
+                else:
+                    ops.bmu_cosine_x3_fwd(x2d, W, s.dist, s.bmu, s.inx, s.inw, s.reranked)
             else:
                 ops.row_inv_norm(x2d, s.inx)
                 ops.row_inv_norm(W, s.inw)
@@ -870,8 +932,22 @@ class FusedAdamW(torch.optim.Optimizer):
         if len(lrs) != 1:
             raise RuntimeError("FusedAdamW: per-group learning rates differ; the arena kernel uses one lr")
         b1, b2 = g0["betas"]
+        som = getattr(m, "som_layer", None)
+        planes = None
+        if som is not None and som._planes_used and hooks.bmu_planes and hooks.adamw_planes:
+            # the prototypes' plane image for the next BMU pass leaves the same kernel that updates them
+            name = next((n for n, q in m._named_trainable() if q is som.prototypes), None)
+            W = som.prototypes
+            if name is not None and W.dim() == 2 and W.shape[1] % 8 == 0 and ops.get_gemm_mode() != ops.GEMM_F32:
+                if som._wplanes is None or som._wplanes.device != W.device:
+                    som._wplanes = ops.bmu_planes_alloc(W.shape[0], W.shape[1], W.device)
+                planes = (m.arena.offsets[name][0], W.shape[0], W.shape[1], som._wplanes)
         ops.adamw_step(m.arena.params, m.arena.grads, m.arena.exp_avg, m.arena.exp_avg_sq, m.arena.wd_chunk,
-                       float(g0["lr"]), b1, b2, g0["eps"], self._step, grad_scale=1.0 / m.world_size, adamw=self._adamw)
+                       float(g0["lr"]), b1, b2, g0["eps"], self._step, grad_scale=1.0 / m.world_size, adamw=self._adamw,
+                       planes=planes)
+        if som is not None:
+            som._raw_updates += 1                                # the kernel writes through raw pointers
+            som._wplanes_stamp = som._w_stamp() if planes is not None else None
         return loss
 
     def zero_grad(self, set_to_none: bool = True):
@@ -1283,15 +1359,19 @@ class ViTSOM(_ArenaOwner, _Base):
         return torch.as_strided(buf, (a.B, E), (a.N * E, 1), buf.storage_offset())
 
     @torch.no_grad()
-    def _run_forward(self, x, need_decoder: bool):
+    def _run_forward(self, x, need_decoder: bool, fresh_w: bool = False):
         x = self.vit._check_input(x)
         if not x.is_cuda:
             raise ValueError("ViTSOM: input must live on the MI355X (there is no CPU path)")
         a = self.vit._buffers_for(x.shape[0], x.device)
         self._ensure_streams(x.device)
+        # the prototypes' plane image for the BMU pass: re-split on the SOM stream while the encoder runs
+        w_ready = self.som_layer._w_planes_async(self._som_stream, fresh_w) if self.som_layer._planes_shape_ok(a.B) else None
         self.vit._encode(x, a)
         if need_decoder:
             self.vit._decode(a)
+        if w_ready is not None:
+            w_ready.wait()
         s = self.som_layer._buffers_for(a.B, x.device)
         self.som_layer._distances_into(self._som_input(a), s)
         if self.classification:
@@ -1357,7 +1437,9 @@ class ViTSOM(_ArenaOwner, _Base):
     def _forward_losses(self, x, y, gamma_t: float, T: float, want_grad: bool):
         """All forward kernels + both losses (+ loss-side gradients when want_grad).  Returns the
         total loss as a 0-dim device tensor; parts land in self._last."""
-        x, a, s = self._run_forward(x, need_decoder=not self.classification)
+        # (a training step always re-splits the prototypes unless the optimizer keeps their image: a recorded step must
+        # not depend on the state it was recorded in)
+        x, a, s = self._run_forward(x, need_decoder=not self.classification, fresh_w=want_grad and not hooks.adamw_planes)
         B = a.B
         self._ctx = (x, a, s)
         self._forward_id, self._seeds_consumed = self._forward_id + 1, False
@@ -1506,7 +1588,7 @@ class ViTSOM(_ArenaOwner, _Base):
     # persistent per batch size, so the tape lives and dies with the activation buffers (`a`).
     def _tape_key(self):
         return (ops.get_gemm_mode(), hooks.side_stream, hooks.fwd_split, hooks.fwd_split_blocks, hooks.overlap_allreduce,
-                hooks.bucket_blocks, self.world_size, self._use_vsom_comm, id(self.arena))
+                hooks.bucket_blocks, self.world_size, self._use_vsom_comm, id(self.arena), hooks.bmu_planes, hooks.adamw_planes, id(self.som_layer._wplanes))
 
     def _tape_usable(self, x) -> bool:
         return bool(hooks.launch_tape and x.is_cuda and (self.world_size == 1 or self._use_vsom_comm) and ops.tape_recording() == 0)
@@ -1534,6 +1616,8 @@ class ViTSOM(_ArenaOwner, _Base):
         if tape is not None and (tape.key != self._tape_key() or tape.som_bufs is not self.som_layer._bufs.get(a.B)):
             tape.close()
             tape = a.tape = None
+        if hooks.adamw_planes and self.som_layer._planes_shape_ok(a.B):
+            self.som_layer._w_planes()                # outside the tape: launches only when the optimizer-kept image is stale
         if tape is None:
             a.steps_seen += 1
             if a.steps_seen <= 2:                     # host-driven: scratch buffers and lazily built tables settle first

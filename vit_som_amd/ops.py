@@ -318,6 +318,53 @@ def bmu_cosine_x3_fwd(x, W, dist: Optional[torch.Tensor], bmu, inv_nx, inv_nw, r
     return dist, bmu
 
 
+def bmu_planes_supported(B: int, K: int, L: int) -> bool:
+    """Does the pre-split ("planes") form of the cosine BMU pass cover this shape?"""
+    return bool(lib.vsom_bmu_cosine_x3_planes_supported(int(B), int(K), int(L)))
+
+
+def bmu_planes_alloc(R: int, L: int, device) -> torch.Tensor:
+    """Plane buffer of an operand [R, L] (fragment image + squared-norm partials)."""
+    return torch.empty(lib.vsom_bmu_planes_bytes(int(R), int(L)), dtype=torch.uint8, device=device)
+
+
+def bmu_planes_from(src, planes):
+    """Split the fp32 operand `src` [R, L] (rows 16-byte aligned) into its plane buffer."""
+    R, L = src.shape
+    _f32(src, "src")
+    assert src.stride(1) == 1 and planes.dtype == torch.uint8
+    check(lib.vsom_bmu_planes_from(ptr(src), _rows(src), R, L, ptr(planes), planes.numel(), stream()), "vsom_bmu_planes_from")
+    return planes
+
+
+def bmu_cosine_x3_planes_fwd(x, W, xplanes, wplanes, dist: Optional[torch.Tensor], bmu, inv_nx, inv_nw,
+                             reranked: Optional[torch.Tensor] = None):
+    """bmu_cosine_x3_fwd on pre-split operands: `xplanes` / `wplanes` must describe `x` / `W` as they are now (x and W
+    themselves feed the exact re-rank)."""
+    B, L = x.shape
+    K = W.shape[0]
+    _f32(x, "x"); _f32(W, "W"); _f32(inv_nx, "inv_nx"); _f32(inv_nw, "inv_nw")
+    assert W.is_contiguous() and W.shape[1] == L and bmu.dtype == torch.int64 and (dist is None or dist.is_contiguous())
+    assert reranked is None or (reranked.dtype == torch.int32 and reranked.is_cuda)
+    nbytes = lib.vsom_bmu_cosine_x3_planes_workspace_bytes(B, K, L)
+    if nbytes == 0:
+        raise ValueError(f"bmu_cosine_x3_planes_fwd: shape B={B} K={K} L={L} is not covered by the planes form")
+    ws = scratch(nbytes, x.device)
+    rec = _timers.get("bmu_cosine_dots")
+    if rec is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    check(lib.vsom_bmu_cosine_x3_planes_dots(ptr(xplanes), ptr(wplanes), B, K, L, ptr(ws), ws.numel(), stream()),
+          "vsom_bmu_cosine_x3_planes_dots")
+    if rec is not None:
+        e1.record()
+        rec.append((e0, e1))
+    check(lib.vsom_bmu_cosine_x3_planes_finalize(ptr(x), _rows(x), ptr(W), ptr(xplanes), ptr(wplanes), ptr(ws), ws.numel(),
+                                                 ptr(dist), ptr(bmu), ptr(inv_nx), ptr(inv_nw), ptr(reranked), B, K, L, stream()),
+          "vsom_bmu_cosine_x3_planes_finalize")
+    return dist, bmu
+
+
 def bmu_cosine_fwd(x, W, inv_nx, inv_nw, dist: Optional[torch.Tensor], bmu):
     B, L = x.shape
     K = W.shape[0]
@@ -380,8 +427,16 @@ def cross_entropy_ls(logits, y, smoothing, loss_sum, dlogits=None, grad_scale=0.
 
 
 # ---------------------------------------------------------------- optimiser / utilities
-def adamw_step(p, g, m, v, wd_chunk, lr, beta1, beta2, eps, step, grad_scale=1.0, adamw=True):
+def adamw_step(p, g, m, v, wd_chunk, lr, beta1, beta2, eps, step, grad_scale=1.0, adamw=True, planes=None):
+    """One AdamW / Adam step over the flat arena.  `planes` = (element offset, R, L, plane buffer) of a [R, L] parameter
+    whose BMU plane image is rewritten from the updated values in the same pass."""
     n = p.numel()
+    if planes is not None:
+        off, R, L, buf = planes
+        check(lib.vsom_adamw_step_planes(ptr(p), ptr(g), ptr(m), ptr(v), ptr(wd_chunk), n, float(lr), float(beta1), float(beta2),
+                                         float(eps), int(step), float(grad_scale), int(adamw), int(off), int(R), int(L), ptr(buf),
+                                         buf.numel(), stream()), "vsom_adamw_step_planes")
+        return
     check(lib.vsom_adamw_step(ptr(p), ptr(g), ptr(m), ptr(v), ptr(wd_chunk), n, float(lr), float(beta1), float(beta2),
                               float(eps), int(step), float(grad_scale), int(adamw), stream()), "vsom_adamw_step")
 

@@ -12,6 +12,9 @@ class _Hooks:
     fwd_split_blocks = None     # how many encoder blocks run as two chains (None = all)
     overlap_allreduce = True    # N > 1: issue the all-reduce pieces inside the backward pass
     bucket_blocks = 3           # encoder blocks per early all-reduce piece
+    bmu_planes = True           # cosine BMU pass on pre-split plane images where the shape allows (model.py SOMLayer._distances_into)
+    adamw_planes = False        # True: FusedAdamW writes the prototypes' plane image in its own pass (+27 us on the critical path);
+                                # False: the training forward re-splits them on the SOM stream under the encoder (hidden)
     launch_tape = True          # train_step_fused / training_step re-issue the recorded launches of a step from C (model.py)
 
     def set(self, **kw):
