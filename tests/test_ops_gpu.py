@@ -516,7 +516,8 @@ def test_bmu_exact_ties_pick_lowest_index(ops):
 
 
 @pytest.mark.parametrize("B,K,L,map_size,topo", [(70, 15, 256, (3, 5), "square"), (64, 576, 3136, (24, 24), "square"),
-                                                  (33, 12, 48, (4, 3), "hexa")])
+                                                  (33, 12, 48, (4, 3), "hexa"),
+                                                  (128, 576, 3072, (24, 24), "square")])     # the last: weight-gradient-engine form
 def test_som_neigh_loss_and_bwd(ops, O, gemm_mode, B, K, L, map_size, topo):
     Nrow = L + 8
     xfull = rnd(B, Nrow, seed=1)
@@ -625,7 +626,8 @@ def test_errors_are_loud(ops):
         ops.linear_fwd(torch.empty(4, 4), torch.empty(4, 4), None, torch.empty(4, 4))   # CPU tensors
 
 
-@pytest.mark.parametrize("B,K,L,map_size,topo", [(64, 100, 3136, (10, 10), "square"), (33, 12, 48, (4, 3), "hexa")])
+@pytest.mark.parametrize("B,K,L,map_size,topo", [(64, 100, 3136, (10, 10), "square"), (33, 12, 48, (4, 3), "hexa"),
+                                                  (64, 64, 384, (8, 8), "square")])
 def test_som_euclidean_fwd_and_bwd(ops, O, gemm_mode, B, K, L, map_size, topo):
     """euclidean distance variant (torch.cdist p=2) + its SOM-loss gradients."""
     x = rnd(B, L, seed=1)

@@ -1587,8 +1587,8 @@ class ViTSOM(_ArenaOwner, _Base):
     # with this step's temperature and gamma.  Inputs are staged into fixed buffers; every other buffer of the step is
     # persistent per batch size, so the tape lives and dies with the activation buffers (`a`).
     def _tape_key(self):
-        return (ops.get_gemm_mode(), hooks.side_stream, hooks.fwd_split, hooks.fwd_split_blocks, hooks.overlap_allreduce,
-                hooks.bucket_blocks, self.world_size, self._use_vsom_comm, id(self.arena), hooks.bmu_planes, hooks.adamw_planes, id(self.som_layer._wplanes))
+        return (ops.get_gemm_mode(), ops.get_attention_fused(), hooks.signature(),
+                self.world_size, self._use_vsom_comm, id(self.arena), id(self.som_layer._wplanes))
 
     def _tape_usable(self, x) -> bool:
         return bool(hooks.launch_tape and x.is_cuda and (self.world_size == 1 or self._use_vsom_comm) and ops.tape_recording() == 0)

@@ -449,7 +449,17 @@ def fill(t, value):
 def set_attention_fused(fused):
     """Test / measurement hook: False (0) runs the short-sequence attention backward as two launches, True (1) is the
     default (one launch, scores shared between its phases where the shape allows), 2 = one launch with recomputed scores."""
+    global _attention_fused
     check(lib.vsom_set_attention_fused(int(fused)), "vsom_set_attention_fused")
+    _attention_fused = int(fused)
+
+
+_attention_fused = 1
+
+
+def get_attention_fused() -> int:
+    """The value last set through set_attention_fused (the library's default otherwise)."""
+    return _attention_fused
 
 
 def scaled_mul(out, a, b=None, scale_dev=None, factor=1.0):

@@ -24,6 +24,10 @@ class _Hooks:
             setattr(self, k, v)
         return self
 
+    def signature(self):
+        """All switches as a tuple: what a recorded launch sequence was recorded under (model.py _tape_key)."""
+        return tuple((k, getattr(self, k)) for k in sorted(vars(_Hooks)) if not k.startswith("_") and not callable(getattr(_Hooks, k)))
+
     def reset(self):
         for k in list(self.__dict__):
             delattr(self, k)
