@@ -19,8 +19,16 @@ rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS
 echo "sq insts done"
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d "$OUT/ev_pmc_t" -o a -- python3 "$ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/ev_pmc_t.log" 2>&1
 echo "sq cycles done"
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$OUT/ev_pmc_m" -o a -- python3 "$ROOT/bench.py" --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/ev_pmc_m.log" 2>&1
+echo "mfma busy done"
 python3 "$ROOT/tools/layer_gemms.py" > "$OUT/ev_layer_gemms.log" 2>&1
 echo "layer gemms done"
+python3 "$ROOT/tools/host_vs_gpu.py" > "$OUT/ev_host_vs_gpu.log" 2>&1
+echo "host vs gpu done"
+python3 "$ROOT/tools/accuracy_modes.py" > "$OUT/ev_accuracy_modes.log" 2>&1
+echo "accuracy done"
+(cd "$ROOT" && ./lab/bmu_planes_lab > "$OUT/ev_bmu_planes_lab.log" 2>&1) || true
+echo "bmu lab done"
 # keep what travels back small: the per-dispatch traces are large, the tables are built from these files only
 find "$OUT"/ev_* -name "*_kernel_trace.csv" -size +20M -delete 2>/dev/null || true
 du -sh "$OUT"/ev_* | tail -12

@@ -37,7 +37,13 @@ def c4_config(B):
     c["data"]["num_classes"] = 100
     return c
 
+from vit_som_amd.tuning import hooks
+run(64, bench.c3_config, steps=10)          # the first model of a process pays one-time costs (code objects, allocator): not measured
 for name, fn, Bs in (("c3 (40x40 SOM, clustering)", bench.c3_config, (64, 128, 256, 512)), ("c4 (4x4 SOM, 100 classes)", c4_config, (128,))):
     for B in Bs:
-        ms, enq, alone = run(B, fn)
-        print(f"{name:32s} batch {B:4d}: {ms:6.2f} ms/step = {B / ms * 1e3:8.0f} img/s | host enqueue {enq:5.2f} ms/step | one step alone (events) {alone:5.2f} ms", flush=True)
+        for tape in (True, False):
+            hooks.set(launch_tape=tape)
+            ms, enq, alone = run(B, fn)
+            print(f"{name:28s} batch {B:4d} launch tape {'on ' if tape else 'off'}: {ms:6.2f} ms/step = {B / ms * 1e3:8.0f} img/s | host enqueue {enq:5.2f} ms/step | "
+                  f"one step alone (events) {alone:5.2f} ms", flush=True)
+hooks.reset()

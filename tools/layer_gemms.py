@@ -1,5 +1,6 @@
 """The twelve GEMMs of one encoder layer at the c3 shapes, each alone: time, f32-equivalent TFLOP/s, HBM GB/s,
-and the two floors (bytes at 5 TB/s; six bf16 products at 2500 TFLOP/s)."""
+and the two floors (bytes at 5 TB/s; the GEMM's bf16 products -- six in the forward, three in the gradient GEMMs of the default
+mode -- at 2500 TFLOP/s)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -37,9 +38,11 @@ rows = [
     ("dW qkv    [576,192] over T", lambda: ops.linear_bwd_weight(y3, x, dW["qkv"], db["qkv"]), 576, 192, T, 4 * (T * 576 + T * 192)),
 ]
 tot = 0.0
+grad3 = ops.get_gemm_mode() == ops.GEMM_SPLIT_BF16_GRAD3
 for name, fn, M, N, K, nbytes in rows:
     us = t_us(fn)
     tot += us
     fl = 2.0 * M * N * K
-    print(f"{name:30s} {us:7.1f} us  {fl/us/1e6:6.1f} TF  {nbytes/us/1e3:7.1f} GB/s   floors: hbm {nbytes/5e6:6.1f} us, mfma {6*fl/2.5e9:6.1f} us")
+    prod = 3 if (grad3 and not name.startswith("fwd")) else 6
+    print(f"{name:30s} {us:7.1f} us  {fl/us/1e6:6.1f} TF  {nbytes/us/1e3:7.1f} GB/s   floors: hbm {nbytes/5e6:6.1f} us, mfma {prod*fl/2.5e9:6.1f} us   products {prod}")
 print(f"sum {tot:.0f} us per layer (x12 encoder layers = {tot*12/1e3:.2f} ms)")

@@ -1074,6 +1074,9 @@ def init_vsom_comm(world_size: int, rank: int, unique_id: Optional[bytes] = None
 
 
 # ------------------------------------------------------------------------------------ arena owner
+_STEP_STREAMS: Dict[int, tuple] = {}        # device index -> (side stream, SOM stream), shared by every model of the process
+
+
 class _ArenaOwner:
     """What every model on this path shares: trainable tensors packed into flat arenas
     (arena.py), gradients exposed as views, and the data-parallel exchange over the gradient
@@ -1462,8 +1465,15 @@ class ViTSOM(_ArenaOwner, _Base):
     def _ensure_streams(self, device):
         """The two extra HIP streams of the step (kept to two: a process has few hardware queues)."""
         if getattr(self, "_side_stream", None) is None or self._side_stream.device != device:
-            self._side_stream = torch.cuda.Stream(device=device)      # weight-gradient GEMMs; second forward chain
-            self._som_stream = torch.cuda.Stream(device=device)       # SOM backward + early all-reduce
+            # one pair per device for the whole process: which hardware queue a stream lands on depends on how many
+            # streams the process has created, and two of a model's streams on one queue serialise (measured: the 3rd, 5th
+            # ... model of a process ran its step 1.4x slower at batch 128)
+            key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+            pair = _STEP_STREAMS.get(key)
+            if pair is None:
+                pair = _STEP_STREAMS[key] = (torch.cuda.Stream(device=device), torch.cuda.Stream(device=device))
+            self._side_stream = pair[0]      # weight-gradient GEMMs; second forward chain
+            self._som_stream = pair[1]       # SOM backward + early all-reduce; the prototypes' plane image in the forward
         self.vit.__dict__["_lent_stream"] = self._side_stream
 
     @torch.no_grad()
