@@ -135,6 +135,18 @@ size_t vsom_layernorm_bwd_workspace_bytes(int rows, int cols);
 int vsom_layernorm_bwd(const float* dY, const float* X, const float* mean, const float* rstd,
                        const float* gamma, const float* resid, float* dX, float* dgamma, float* dbeta,
                        int rows, int cols, void* ws, size_t ws_bytes, vsom_stream_t stream);
+/* The same in two halves (autograd of nn.LayerNorm, vit.py:48,50,85,95): _partial computes dX and leaves the column
+ * partials in `part` (vsom_layernorm_bwd_workspace_bytes, kept by the caller); one vsom_layernorm_bwd_finish_many launch
+ * then produces dgamma / dbeta for `count` such calls, bit for bit what vsom_layernorm_bwd would have written (the step's
+ * 30 tiny reductions leave its critical chain).  jobs_dev: device array of VSOM_LN_JOB_WORDS 64-bit words per job --
+ * part, dgamma, dbeta (pointers), (nblk << 32) | cols with nblk = workspace_bytes / (8 cols); jobs first .. first+count-1
+ * are reduced, max_cols = the widest of them.  Shapes: vsom_layernorm_bwd_deferrable(rows, cols) != 0. */
+#define VSOM_LN_JOB_WORDS 4
+int vsom_layernorm_bwd_deferrable(int rows, int cols);
+int vsom_layernorm_bwd_partial(const float* dY, const float* X, const float* mean, const float* rstd,
+                               const float* gamma, const float* resid, float* dX, int rows, int cols, void* part,
+                               size_t part_bytes, vsom_stream_t stream);
+int vsom_layernorm_bwd_finish_many(const int64_t* jobs_dev, int first, int count, int max_cols, vsom_stream_t stream);
 
 /* ------------------------------------------------------------------ multi-head attention */
 /* out[B,N,H*hd] = softmax(q k^T * hd^-0.5) v, qkv laid out [B,N,3,H,hd] (the qkv Linear's

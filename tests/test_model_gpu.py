@@ -211,9 +211,10 @@ def test_stream_level_concurrency_is_bitwise_identical():
 
 
 def _run_switch_combinations(cfg, finals, hooks, ops, vit_som_amd):
-    for side, split, nblk, fused in (("0", "0", None, True), ("1", "1", None, True), ("1", "0", None, False), ("0", "1", 2, True),
-                                     ("1", "1", 1, False)):
-        hooks.set(side_stream=side == "1", fwd_split=split == "1", fwd_split_blocks=nblk)
+    # (last column: the LayerNorm backwards' column reductions in one launch per exchange piece, or one launch each)
+    for side, split, nblk, fused, lnb in (("0", "0", None, True, True), ("1", "1", None, True, True), ("1", "0", None, False, False),
+                                          ("0", "1", 2, True, False), ("1", "1", 1, False, True), ("1", "1", None, True, False)):
+        hooks.set(side_stream=side == "1", fwd_split=split == "1", fwd_split_blocks=nblk, ln_reduce_batched=lnb)
         ops.set_attention_fused(fused)
         torch.manual_seed(0)
         m = vit_som_amd.ViTSOM(copy.deepcopy(cfg), device=DEV)
@@ -227,6 +228,8 @@ def _run_switch_combinations(cfg, finals, hooks, ops, vit_som_amd):
             m.train_step_fused(x, y)
             opt.step()
         assert (m.vit._side is not None) == (side == "1")
+        jobs = m.vit._acts[96].__dict__.get("ln_jobs")
+        assert (jobs is not None and jobs.n == jobs.flushed == 2 * (4 + 2) + 2) == lnb      # every LayerNorm of the step went through the batch
         assert (m.vit.__dict__.get("_fwd_side") is not None) == (split == "1")
         assert split == "0" or m.vit._fwd_side is m._side_stream          # the second chain borrows the backward's side stream
         finals.append(m.arena.params.clone())

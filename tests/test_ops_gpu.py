@@ -587,6 +587,40 @@ def test_cross_entropy_ls(ops, B, C):
     assert rel_err(dz.cpu(), zl.grad) < 5e-6
 
 
+def test_layernorm_bwd_in_two_halves_gives_the_same_bits(ops):
+    """vsom_layernorm_bwd_partial + ONE vsom_layernorm_bwd_finish_many for several LayerNorms of different widths, flushed in
+    two groups: dX, dgamma, dbeta bit for bit those of vsom_layernorm_bwd; a second pass reuses the job table."""
+    shapes = [(33280, 192), (33280, 96), (8320, 192), (4160, 64)]
+    data = []
+    for i, (rows, cols) in enumerate(shapes):
+        assert ops.layernorm_bwd_deferrable(rows, cols)
+        x, dy, res = dev(rnd(rows, cols, seed=3 * i)), dev(rnd(rows, cols, seed=3 * i + 1)), dev(rnd(rows, cols, seed=3 * i + 2))
+        gam = dev(rnd(cols, seed=50 + i))
+        y, mean, rstd = torch.empty_like(x), torch.empty(rows, device=DEV), torch.empty(rows, device=DEV)
+        ops.layernorm_fwd(x, gam, torch.zeros(cols, device=DEV), y, mean, rstd, 1e-6)
+        ref = [torch.empty_like(x), torch.empty(cols, device=DEV), torch.empty(cols, device=DEV)]
+        ops.layernorm_bwd(dy, x, mean, rstd, gam, res if i % 2 else None, *ref)
+        data.append((dy, x, mean, rstd, gam, res if i % 2 else None, ref))
+    jobs = ops.LayerNormJobs(DEV)
+    for rep in range(2):
+        outs = [[torch.full_like(d[1], 7.0), torch.full((d[1].shape[1],), 7.0, device=DEV), torch.full((d[1].shape[1],), 7.0, device=DEV)]
+                for d in data] if rep == 0 else outs
+        for o in outs:
+            for t in o:
+                t.fill_(7.0)
+        jobs.begin()
+        for k, (d, o) in enumerate(zip(data, outs)):
+            jobs.bwd(*d[:6], *o)
+            if k == 1:
+                jobs.flush()
+        jobs.flush()
+        assert jobs.n == jobs.flushed == len(shapes)
+        for d, o in zip(data, outs):
+            for a, b in zip(d[6], o):
+                assert torch.equal(a, b), rep
+    assert not ops.layernorm_bwd_deferrable(100, 192)             # too few workgroups for the wide reducer: the one-call form
+
+
 def test_adamw_step(ops):
     n = 256 * 5
     g0 = torch.Generator().manual_seed(0)

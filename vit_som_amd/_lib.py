@@ -43,6 +43,9 @@ SIGNATURES = {
     "vsom_layernorm_fwd": (C.c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, C.c_int, C.c_int, C.c_float, c_stream]),
     "vsom_layernorm_bwd_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "vsom_layernorm_bwd": (C.c_int, [c_fp] * 9 + [C.c_int, C.c_int, c_fp, C.c_size_t, c_stream]),
+    "vsom_layernorm_bwd_deferrable": (C.c_int, [C.c_int, C.c_int]),
+    "vsom_layernorm_bwd_partial": (C.c_int, [c_fp] * 7 + [C.c_int, C.c_int, c_fp, C.c_size_t, c_stream]),
+    "vsom_layernorm_bwd_finish_many": (C.c_int, [c_fp, C.c_int, C.c_int, C.c_int, c_stream]),
     "vsom_attention_fwd": (C.c_int, [c_fp, c_fp, c_fp, C.c_int, C.c_int, C.c_int, C.c_int, c_stream]),
     "vsom_attention_bwd": (C.c_int, [c_fp] * 6 + [C.c_int] * 4 + [c_stream]),
     "vsom_set_attention_fused": (C.c_int, [C.c_int]),

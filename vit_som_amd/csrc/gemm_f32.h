@@ -478,6 +478,65 @@ int launch_gemm(bool a_kc, bool b_kc, int epi, GemmP g, int splits, hipStream_t 
 int linear_bwd_weight_impl(const float* dY, long lddy, const float* X, long ldx, float* dW, float* db, int M, int N,
                            int K, int a_seg, int a_stride, int a_off, void* ws, size_t ws_bytes,
                            hipStream_t stream);
+// out1[j] = sum_s slabs[s*stride + j]            (j < n1)
+// out2[j] = sum_s slabs[s*stride + off2 + j]     (j < n2; optional second segment, e.g. the bias)
+// A workgroup owns 256 consecutive columns (64 lanes x float4); its WAVES waves stride over the
+// slabs with four independent accumulators each (loads in flight instead of one dependent chain)
+// and are combined through LDS in wave order: the summation order is fixed -> bitwise reproducible.
+template <int WAVES, int VEC>
+__device__ __forceinline__ void reduce_slabs_body(f32x4 (*sh)[64], int bx, const float* __restrict__ slabs, long stride,
+                                                  int nslabs, float* __restrict__ out1, long n1,
+                                                  float* __restrict__ out2, long off2, long n2,
+                                                  int nb1, int vec) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool seg2 = bx >= nb1;
+    const long col = ((long)(seg2 ? bx - nb1 : bx) * 64 + lane) * VEC;
+    const long n = seg2 ? n2 : n1;
+    const float* src = slabs + (seg2 ? off2 : 0) + col;
+    f32x4 acc[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (col < n) {
+        if (VEC == 4 && vec && col + 3 < n) {
+            int s = wave;
+            for (; s + 3 * WAVES < nslabs; s += 4 * WAVES) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc[u] += *reinterpret_cast<const f32x4*>(src + (long)(s + u * WAVES) * stride);
+            }
+            for (; s < nslabs; s += WAVES) acc[0] += *reinterpret_cast<const f32x4*>(src + (long)s * stride);
+        } else if (VEC == 1) {                           // narrow outputs (LayerNorm / bias): one column per lane
+            int s = wave;
+            for (; s + 3 * WAVES < nslabs; s += 4 * WAVES) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc[u][0] += src[(long)(s + u * WAVES) * stride];
+            }
+            for (; s < nslabs; s += WAVES) acc[0][0] += src[(long)s * stride];
+        } else {
+            for (int s = wave; s < nslabs; s += WAVES)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (col + e < n) acc[0][e] += src[(long)s * stride + e];
+        }
+    }
+    sh[wave][lane] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    __syncthreads();
+    if (wave == 0 && col < n) {
+        f32x4 t = sh[0][lane];
+#pragma unroll
+        for (int w = 1; w < WAVES; ++w) t += sh[w][lane];
+        float* dst = (seg2 ? out2 : out1) + col;
+        if (VEC == 1) {
+            dst[0] = t[0];
+        } else if (col + 3 < n && (reinterpret_cast<uintptr_t>(dst) & 15u) == 0) {
+            *reinterpret_cast<f32x4*>(dst) = t;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (col + e < n) dst[e] = t[e];
+        }
+    }
+}
+
 int reduce_slabs_internal(const float* slabs, long stride, int nslabs, float* out, long n, hipStream_t stream);
 int reduce_slabs2_internal(const float* slabs, long stride, int nslabs, float* out1, long n1, float* out2, long off2,
                            long n2, hipStream_t stream);

@@ -231,6 +231,21 @@ __global__ __launch_bounds__(256) void layernorm_bwd_v4_kernel(const float* __re
     }
 }
 
+// One launch for the column reductions of many LayerNorm backwards.  A job = four 64-bit words: the partials
+// [nblk][2 cols], dgamma, dbeta, (nblk << 32) | cols.  blockIdx.y = job, blockIdx.x as in reduce_slabs_kernel<16, 1>.
+__global__ __launch_bounds__(1024) void ln_finish_many_kernel(const int64_t* __restrict__ jobs) {
+    __shared__ __attribute__((aligned(16))) f32x4 sh[16][64];
+    const int64_t* j = jobs + (long)blockIdx.y * VSOM_LN_JOB_WORDS;
+    const float* part = reinterpret_cast<const float*>(j[0]);
+    float* dgamma = reinterpret_cast<float*>(j[1]);
+    float* dbeta = reinterpret_cast<float*>(j[2]);
+    const int nblk = (int)(j[3] >> 32), cols = (int)(j[3] & 0xffffffff);
+    const int nb1 = (cols + 63) / 64;
+    if ((int)blockIdx.x >= 2 * nb1) return;                    // a job narrower than the widest of the launch
+    const int vec = ((reinterpret_cast<uintptr_t>(part) & 15u) == 0) && ((2L * cols) % 4 == 0) && (cols % 4 == 0);
+    reduce_slabs_body<16, 1>(sh, (int)blockIdx.x, part, 2L * cols, nblk, dgamma, cols, dbeta, cols, cols, nb1, vec);
+}
+
 static int ln_bwd_blocks(int rows) {
     // one partial [2][cols] per workgroup goes through the slab reducer afterwards (a handful of
     // workgroups walking all partials): 512 workgroups of 4 x 16 rows keep ~9 KB of loads in flight per
@@ -275,16 +290,9 @@ size_t vsom_layernorm_bwd_workspace_bytes(int rows, int cols) {
     return (size_t)ln_bwd_blocks(rows) * 2 * (size_t)cols * sizeof(float);
 }
 
-int vsom_layernorm_bwd(const float* dY, const float* X, const float* mean, const float* rstd, const float* gamma,
-                       const float* resid, float* dX, float* dgamma, float* dbeta, int rows, int cols, void* ws,
-                       size_t ws_bytes, vsom_stream_t stream) {
-    VSOM_REQUIRE(dY && X && mean && rstd && gamma && dX && dgamma && dbeta, VSOM_EINVAL, "layernorm_bwd: null pointer");
-    VSOM_REQUIRE(rows > 0 && cols > 0, VSOM_EINVAL, "layernorm_bwd: bad shape");
-    VSOM_REQUIRE(cols <= 1024, VSOM_EUNSUPPORTED, "layernorm_bwd: cols=%d > 1024", cols);
-    VSOM_REQUIRE(ws && ws_bytes >= vsom_layernorm_bwd_workspace_bytes(rows, cols), VSOM_EWORKSPACE, "layernorm_bwd: workspace too small");
-    VSOM_REQUIRE(aligned16(ws), VSOM_EALIGN, "layernorm_bwd: workspace must be 16-byte aligned");
+static int ln_bwd_launch(const float* dY, const float* X, const float* mean, const float* rstd, const float* gamma,
+                         const float* resid, float* dX, int rows, int cols, float* part, hipStream_t stream) {
     const int nblk = ln_bwd_blocks(rows);
-    float* part = static_cast<float*>(ws);
     const size_t shmem = (size_t)8 * cols * sizeof(float);
     const bool v4 = cols % 4 == 0 && cols <= 256 && aligned16(dY) && aligned16(X) && aligned16(gamma) && aligned16(dX) &&
                     (!resid || aligned16(resid));
@@ -299,9 +307,47 @@ int vsom_layernorm_bwd(const float* dY, const float* X, const float* mean, const
         VSOM_LAUNCH(layernorm_bwd_kernel<4>, dim3(nblk), dim3(256), shmem, stream, dY, X, mean, rstd, gamma, resid, dX, part, rows, cols);
     else
         VSOM_LAUNCH(layernorm_bwd_kernel<16>, dim3(nblk), dim3(256), shmem, stream, dY, X, mean, rstd, gamma, resid, dX, part, rows, cols);
-    int rc = hip_status(hipGetLastError(), "layernorm_bwd_kernel");
+    return hip_status(hipGetLastError(), "layernorm_bwd_kernel");
+}
+
+int vsom_layernorm_bwd(const float* dY, const float* X, const float* mean, const float* rstd, const float* gamma,
+                       const float* resid, float* dX, float* dgamma, float* dbeta, int rows, int cols, void* ws,
+                       size_t ws_bytes, vsom_stream_t stream) {
+    VSOM_REQUIRE(dY && X && mean && rstd && gamma && dX && dgamma && dbeta, VSOM_EINVAL, "layernorm_bwd: null pointer");
+    VSOM_REQUIRE(rows > 0 && cols > 0, VSOM_EINVAL, "layernorm_bwd: bad shape");
+    VSOM_REQUIRE(cols <= 1024, VSOM_EUNSUPPORTED, "layernorm_bwd: cols=%d > 1024", cols);
+    VSOM_REQUIRE(ws && ws_bytes >= vsom_layernorm_bwd_workspace_bytes(rows, cols), VSOM_EWORKSPACE, "layernorm_bwd: workspace too small");
+    VSOM_REQUIRE(aligned16(ws), VSOM_EALIGN, "layernorm_bwd: workspace must be 16-byte aligned");
+    float* part = static_cast<float*>(ws);
+    const int rc = ln_bwd_launch(dY, X, mean, rstd, gamma, resid, dX, rows, cols, part, stream);
     if (rc) return rc;
-    return reduce_slabs2_internal(part, 2L * cols, nblk, dgamma, cols, dbeta, cols, cols, stream);
+    return reduce_slabs2_internal(part, 2L * cols, ln_bwd_blocks(rows), dgamma, cols, dbeta, cols, cols, stream);
+}
+
+/* The same in two halves, for a caller that runs many LayerNorm backwards before anybody needs their dgamma / dbeta:
+   _partial does everything but the column reduction (its partials stay in `part`, which the caller keeps), and ONE
+   vsom_layernorm_bwd_finish_many launch reduces the partials of `count` such calls -- same kernel body, same order,
+   same bits as vsom_layernorm_bwd (30 six-workgroup launches on the step's critical chain become one). */
+int vsom_layernorm_bwd_deferrable(int rows, int cols) {
+    // the shapes whose reduction vsom_layernorm_bwd runs in the one-column-per-lane form (reduce_slabs2_internal)
+    return rows > 0 && cols > 0 && cols <= 1024 && 2L * cols <= 4096 && ln_bwd_blocks(rows) >= 32;
+}
+
+int vsom_layernorm_bwd_partial(const float* dY, const float* X, const float* mean, const float* rstd, const float* gamma,
+                               const float* resid, float* dX, int rows, int cols, void* part, size_t part_bytes,
+                               vsom_stream_t stream) {
+    VSOM_REQUIRE(dY && X && mean && rstd && gamma && dX, VSOM_EINVAL, "layernorm_bwd_partial: null pointer");
+    VSOM_REQUIRE(vsom_layernorm_bwd_deferrable(rows, cols), VSOM_EUNSUPPORTED, "layernorm_bwd_partial: shape rows=%d cols=%d", rows, cols);
+    VSOM_REQUIRE(part && aligned16(part) && part_bytes >= vsom_layernorm_bwd_workspace_bytes(rows, cols), VSOM_EWORKSPACE,
+                 "layernorm_bwd_partial: partial buffer too small or misaligned");
+    return ln_bwd_launch(dY, X, mean, rstd, gamma, resid, dX, rows, cols, static_cast<float*>(part), stream);
+}
+
+int vsom_layernorm_bwd_finish_many(const int64_t* jobs_dev, int first, int count, int max_cols, vsom_stream_t stream) {
+    VSOM_REQUIRE(jobs_dev && first >= 0 && count >= 0 && max_cols > 0 && 2L * max_cols <= 4096, VSOM_EINVAL, "layernorm_bwd_finish_many: bad arguments");
+    if (count == 0) return VSOM_OK;
+    VSOM_LAUNCH(ln_finish_many_kernel, dim3(2 * cdiv(max_cols, 64), count), dim3(1024), 0, stream, jobs_dev + (long)first * VSOM_LN_JOB_WORDS);
+    VSOM_LAUNCH_CHECK("ln_finish_many_kernel");
 }
 
 }  // extern "C"

@@ -462,6 +462,14 @@ class ViTAutoencoder(nn.Module):
         if self._side is not None:
             self.__dict__.setdefault("_side_pending", []).append(self._event().record(self._side))
 
+    def _ln_bwd(self, dy, x, mean, rstd, gamma, resid, dx, dgamma, dbeta):
+        """LayerNorm backward; with a job list lent by the owner (ViTSOM._backward) the dgamma / dbeta reduction is
+        left to the owner's next flush."""
+        jobs = self.__dict__.get("_ln_jobs")
+        if jobs is not None and ops.layernorm_bwd_deferrable(*x.shape):
+            return jobs.bwd(dy, x, mean, rstd, gamma, resid, dx, dgamma, dbeta)
+        return ops.layernorm_bwd(dy, x, mean, rstd, gamma, resid, dx, dgamma, dbeta)
+
     def _block_bwd(self, blk: Block, L: _Acts, x_in, gout, a: _Acts, G, prefix: str, bufs, WT=None, parity: int = 0):
         """gout: gradient w.r.t. the block output [T,dim]; returns gradient w.r.t. x_in (in bufs)."""
         T, dim, hid = a.T, blk.dim, blk.hidden
@@ -474,14 +482,14 @@ class ViTAutoencoder(nn.Module):
         self._dx(WT, gout, blk.mlp["2"].weight, dh, gelu_grad=L.hpre)
         self._dw(dh, L.a2, G(f"{prefix}.mlp.0.weight"), G(f"{prefix}.mlp.0.bias"))
         self._dx(WT, dh, blk.mlp["0"].weight, da)
-        ops.layernorm_bwd(da, L.x1, L.mean2, L.rstd2, blk.norm2.weight, gout, g1, G(f"{prefix}.norm2.weight"),
+        self._ln_bwd(da, L.x1, L.mean2, L.rstd2, blk.norm2.weight, gout, g1, G(f"{prefix}.norm2.weight"),
                           G(f"{prefix}.norm2.bias"))
         self._dw(g1, L.ao, G(f"{prefix}.attn.proj.weight"), G(f"{prefix}.attn.proj.bias"))
         self._dx(WT, g1, blk.attn.proj.weight, da)
         ops.attention_bwd(L.qkv, L.ao, da, L.lse, dqkv, a.delta, a.B, a.N, blk.heads, dim // blk.heads)
         self._dw(dqkv, L.a1, G(f"{prefix}.attn.qkv.weight"), G(f"{prefix}.attn.qkv.bias"))
         self._dx(WT, dqkv, blk.attn.qkv.weight, da)
-        ops.layernorm_bwd(da, x_in, L.mean1, L.rstd1, blk.norm1.weight, g1, g0, G(f"{prefix}.norm1.weight"),
+        self._ln_bwd(da, x_in, L.mean1, L.rstd1, blk.norm1.weight, g1, g0, G(f"{prefix}.norm1.weight"),
                           G(f"{prefix}.norm1.bias"))
         self._side_mark()
         return g0
@@ -500,7 +508,7 @@ class ViTAutoencoder(nn.Module):
         dn_grad = a.da[:a.T * DE].view(a.T, DE)
         self._dx(WT, a.dpred, self.decoder_pred.weight, dn_grad)
         x_last = a.dec[-1].x2 if a.dec else a.dec0
-        ops.layernorm_bwd(dn_grad, x_last, a.mean_d, a.rstd_d, self.decoder_norm.weight, None, gA,
+        self._ln_bwd(dn_grad, x_last, a.mean_d, a.rstd_d, self.decoder_norm.weight, None, gA,
                           G("decoder_norm.weight"), G("decoder_norm.bias"))
         gout, pos = gA, 0
         for j, i in enumerate(reversed(range(len(self.decoder_blocks)))):
@@ -521,7 +529,7 @@ class ViTAutoencoder(nn.Module):
         ring = self._views(a, E)
         gA = ring[0]
         x_last = a.enc[-1].x2 if a.enc else a.tok0
-        ops.layernorm_bwd(a.d_xe, x_last, a.mean_e, a.rstd_e, self.norm.weight, None, gA, G("norm.weight"), G("norm.bias"))
+        self._ln_bwd(a.d_xe, x_last, a.mean_e, a.rstd_e, self.norm.weight, None, gA, G("norm.weight"), G("norm.bias"))
         gout, pos = gA, 0
         for j, i in enumerate(reversed(range(len(self.blocks)))):
             x_in = a.enc[i - 1].x2 if i > 0 else a.tok0
@@ -1516,6 +1524,20 @@ class ViTSOM(_ArenaOwner, _Base):
             self.vit._side = None
         Gv = self._G("vit.")
         self._refresh_weight_transposes()
+        # the LayerNorm backwards leave their dgamma / dbeta reductions to one launch per exchange piece (or one in all)
+        jobs = None
+        if x.is_cuda and hooks.ln_reduce_batched:
+            jobs = a.__dict__.get("ln_jobs")
+            if jobs is None:
+                jobs = a.ln_jobs = ops.LayerNormJobs(x.device)
+            jobs.begin()
+        self.vit.__dict__["_ln_jobs"] = jobs
+        try:
+            self._backward_body(x, a, s, Gv, jobs)
+        finally:
+            self.vit.__dict__["_ln_jobs"] = None
+
+    def _backward_body(self, x, a, s, Gv, jobs):
         X = self._som_input(a)
         E, N = self.vit.embed_dim, a.N
         if self.use_reduced:
@@ -1536,6 +1558,10 @@ class ViTSOM(_ArenaOwner, _Base):
         def streams_now():
             return [st for st in (main, self.vit._side) if st is not None]
 
+        def flush():
+            if jobs is not None:
+                jobs.flush()
+
         side = self._som_stream if self.vit._side is not None else None
         if self.classification or side is None:
             if self.classification:
@@ -1549,6 +1575,7 @@ class ViTSOM(_ArenaOwner, _Base):
             else:
                 self.vit._decoder_bwd(a, Gv, self._WT)
                 if "decoder" in buckets:
+                    flush()
                     self._reduce_early(*buckets["decoder"], streams=streams_now())
             som_backward(gX, True)
             if "som" in buckets:
@@ -1573,14 +1600,17 @@ class ViTSOM(_ArenaOwner, _Base):
             som_done.record(side)
             self.vit._decoder_bwd(a, Gv, self._WT, before_dxe=lambda: som_done.wait())
             if "decoder" in buckets:
+                flush()
                 self._reduce_early(*buckets["decoder"], streams=streams_now())
 
         def on_block(i):
             b = buckets.get(f"enc{i}")
             if b is not None:
+                flush()
                 self._reduce_early(*b, streams=streams_now())
 
         self.vit._encoder_bwd(a, Gv, self._WT, on_block if buckets else None)
+        flush()
         if self.vit._side is not None:
             stream_wait_stream(None, self.vit._side)     # every gradient is final from here on
             self.vit.__dict__.setdefault("_side_pending", []).clear()

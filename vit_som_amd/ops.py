@@ -223,6 +223,56 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, resid, dx, dgamma, dbeta):
     return dx
 
 
+class LayerNormJobs:
+    """The LayerNorm backwards of one pass in deferred form: `bwd` computes dX and leaves the column partials in a buffer
+    of its own, `flush` produces dgamma / dbeta for everything since the last flush in ONE launch (bit for bit what
+    layernorm_bwd writes).  The job table is fixed after the first pass (same calls in the same order, same buffers);
+    a call that does not match it (other shape, other order) starts a new table."""
+
+    def __init__(self, device):
+        self.device = device
+        self.keys, self.rows_host, self.parts = [], [], []
+        self.table = None               # int64 [njobs, 4] on the device, built once the first pass is complete
+        self.n = self.flushed = 0
+        self.max_cols = 0
+
+    def begin(self):
+        self.n = self.flushed = 0
+
+    def bwd(self, dy, x, mean, rstd, gamma, resid, dx, dgamma, dbeta):
+        rows, cols = x.shape
+        key = (ptr(dgamma), ptr(dbeta), rows, cols)
+        i = self.n
+        if i < len(self.keys) and self.keys[i] != key:           # the pass changed: forget the table from here on
+            del self.keys[i:], self.rows_host[i:], self.parts[i:]
+            self.table = None
+        if i == len(self.keys):
+            nbytes = lib.vsom_layernorm_bwd_workspace_bytes(rows, cols)
+            part = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            self.keys.append(key); self.parts.append(part)
+            self.rows_host.append([ptr(part), ptr(dgamma), ptr(dbeta), ((nbytes // (8 * cols)) << 32) | cols])
+            self.max_cols = max(self.max_cols, cols)
+            self.table = None
+        part = self.parts[i]
+        check(lib.vsom_layernorm_bwd_partial(ptr(dy), ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(resid), ptr(dx), rows, cols,
+                                             ptr(part), part.numel(), stream()), "vsom_layernorm_bwd_partial")
+        self.n += 1
+        return dx
+
+    def flush(self):
+        if self.n == self.flushed:
+            return
+        if self.table is None or self.table.shape[0] < self.n:
+            self.table = torch.tensor(self.rows_host, dtype=torch.int64, device=self.device)
+        check(lib.vsom_layernorm_bwd_finish_many(ptr(self.table), self.flushed, self.n - self.flushed, self.max_cols, stream()),
+              "vsom_layernorm_bwd_finish_many")
+        self.flushed = self.n
+
+
+def layernorm_bwd_deferrable(rows: int, cols: int) -> bool:
+    return bool(lib.vsom_layernorm_bwd_deferrable(int(rows), int(cols)))
+
+
 # ---------------------------------------------------------------- attention
 def attention_fwd(qkv, out, lse, B, N, H, hd):
     assert qkv.is_contiguous() and out.is_contiguous() and lse.is_contiguous()
