@@ -176,6 +176,8 @@ def test_vsom_comm_rccl_one_rank_bucketed_exchange_keeps_the_trajectory():
         if use_comm:
             m.set_distributed(1, 0, backend="rccl")
             assert ops.comm_info() == (1, 0)
+            from vit_som_amd.model import _vsom_comm_selftest
+            assert _vsom_comm_selftest(1, x.device)   # what set_distributed runs at world > 1 before it trusts the communicator
             m.world_size = 2                          # force the N > 1 branches; AdamW's 1/world is undone below
             orig = ops.comm_allreduce_sum
 

@@ -1081,6 +1081,16 @@ def init_vsom_comm(world_size: int, rank: int, unique_id: Optional[bytes] = None
     ops.comm_init(unique_id, world_size, rank)
 
 
+def _vsom_comm_selftest(world_size: int, device) -> bool:
+    """One small sum all-reduce through the library's communicator, checked against the closed form: rank r contributes
+    r + 1 in every element, the sum is world (world + 1) / 2."""
+    _, rank = ops.comm_info()
+    buf = torch.full((1024,), float(rank + 1), dtype=torch.float32, device=device)
+    ops.comm_allreduce_sum(buf)
+    torch.cuda.synchronize(device)
+    return bool((buf == world_size * (world_size + 1) / 2).all().item())
+
+
 # ------------------------------------------------------------------------------------ arena owner
 _STEP_STREAMS: Dict[int, tuple] = {}        # device index -> (side stream, SOM stream), shared by every model of the process
 
@@ -1151,6 +1161,7 @@ class _ArenaOwner:
         runs on gloo), "torch" = torch.distributed's all_reduce (gloo on CPU tensors, or its "nccl" = RCCL)."""
         self.world_size, self.rank = int(world_size), int(rank)
         self.som_layer._world_size = int(world_size)
+        self._backend_defaulted = backend is None
         if backend is None:
             backend = "torch"
             if self.world_size > 1 and self.arena is not None and self.arena.grads.is_cuda:
@@ -1161,7 +1172,30 @@ class _ArenaOwner:
             raise ValueError(f"set_distributed: unknown backend {backend!r}")
         self._use_vsom_comm = backend == "rccl"
         if self._use_vsom_comm:
-            init_vsom_comm(self.world_size, self.rank)
+            chosen_by_default = getattr(self, "_backend_defaulted", False)
+            try:
+                init_vsom_comm(self.world_size, self.rank)
+                ok = self.world_size == 1 or _vsom_comm_selftest(self.world_size, self.arena.grads.device)
+                err = None if ok else "self-test all-reduce gave a wrong sum"
+            except Exception as e:                       # noqa: BLE001 -- a collective backend that does not come up
+                if not chosen_by_default:
+                    raise
+                ok, err = False, repr(e)
+            if chosen_by_default and self.world_size > 1:
+                # every rank takes the same path: agree on it through the process group that is known to work
+                import torch.distributed as dist
+                flag = torch.tensor([1.0 if ok else 0.0], device=self.arena.grads.device)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                all_ok = bool(flag.item() > 0.5)
+                if not all_ok:
+                    import warnings
+                    warnings.warn(f"vit_som_amd: the library's RCCL communicator did not come up on every rank ({err}); "
+                                  f"the gradient exchange uses torch.distributed instead")
+                    self._use_vsom_comm = False
+                    if ops.comm_info()[0] != 0:
+                        ops.comm_destroy()
+            elif not ok:
+                raise RuntimeError(f"set_distributed: vsom_comm {err}")
 
     # -- data-parallel exchange: sum all-reduce over the gradient arena, in pieces -----------------
     # Each piece is a contiguous arena slice whose gradients are final at a known point of the backward
