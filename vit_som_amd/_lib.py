@@ -166,14 +166,26 @@ class on_stream:
 
     def __init__(self, torch_stream):
         self.handle = torch_stream.cuda_stream
+        self.torch_stream = torch_stream
 
     def __enter__(self):
-        global _forced_stream
+        global _forced_stream, _forced_torch_stream
         self.prev, _forced_stream = _forced_stream, self.handle
+        self.prev_t, _forced_torch_stream = _forced_torch_stream, self.torch_stream
 
     def __exit__(self, *exc):
-        global _forced_stream
+        global _forced_stream, _forced_torch_stream
         _forced_stream = self.prev
+        _forced_torch_stream = self.prev_t
+
+
+_forced_torch_stream = None
+
+
+def launch_torch_stream():
+    """The torch Stream object of the stream the next launch goes to (for torch.cuda.Event timing of a library kernel: an
+    event recorded on torch's current stream would not see a kernel launched under ``on_stream``)."""
+    return _forced_torch_stream if _forced_torch_stream is not None else torch.cuda.current_stream()
 
 
 def stream():

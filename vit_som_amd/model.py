@@ -1413,12 +1413,23 @@ class ViTSOM(_ArenaOwner, _Base):
         # the prototypes' plane image for the BMU pass: re-split on the SOM stream while the encoder runs
         w_ready = self.som_layer._w_planes_async(self._som_stream, fresh_w) if self.som_layer._planes_shape_ok(a.B) else None
         self.vit._encode(x, a)
-        if need_decoder:
-            self.vit._decode(a)
-        if w_ready is not None:
-            w_ready.wait()
         s = self.som_layer._buffers_for(a.B, x.device)
-        self.som_layer._distances_into(self._som_input(a), s)
+        if need_decoder and hooks.bmu_overlap and hooks.side_stream:
+            # The BMU pass and the decoder both start from the encoder output and do not meet before the losses: the pass
+            # runs on the SOM stream (behind the prototypes' image, which is written there) under the decoder's
+            # latency-bound kernels.
+            som = self._som_stream
+            Event.pooled().record().wait(som)
+            with on_stream(som):
+                self.som_layer._distances_into(self._som_input(a), s)
+            self.vit._decode(a)
+            Event.pooled().record(som).wait()
+        else:
+            if need_decoder:
+                self.vit._decode(a)
+            if w_ready is not None:
+                w_ready.wait()
+            self.som_layer._distances_into(self._som_input(a), s)
         if self.classification:
             if not hasattr(a, "logits"):
                 a.logits = torch.empty(a.B, self.cls_head.weight.shape[0], dtype=torch.float32, device=x.device)

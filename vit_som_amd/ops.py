@@ -8,6 +8,7 @@ from typing import Optional
 
 import torch
 
+from . import _lib as _lib_mod
 from ._lib import check, lib, ptr, stream
 
 _scratch = {}
@@ -358,10 +359,10 @@ def bmu_cosine_x3_fwd(x, W, dist: Optional[torch.Tensor], bmu, inv_nx, inv_nw, r
     rec = _timers.get("bmu_cosine_dots")
     if rec is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
+        e0.record(_lib_mod.launch_torch_stream())
     check(lib.vsom_bmu_cosine_x3_dots(ptr(x), _rows(x), ptr(W), B, K, L, ptr(ws), ws.numel(), stream()), "vsom_bmu_cosine_x3_dots")
     if rec is not None:
-        e1.record()
+        e1.record(_lib_mod.launch_torch_stream())
         rec.append((e0, e1))
     check(lib.vsom_bmu_cosine_x3_finalize(ptr(x), _rows(x), ptr(W), ptr(ws), ws.numel(), ptr(dist), ptr(bmu), ptr(inv_nx),
                                           ptr(inv_nw), ptr(reranked), B, K, L, stream()), "vsom_bmu_cosine_x3_finalize")
@@ -403,11 +404,11 @@ def bmu_cosine_x3_planes_fwd(x, W, xplanes, wplanes, dist: Optional[torch.Tensor
     rec = _timers.get("bmu_cosine_dots")
     if rec is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
+        e0.record(_lib_mod.launch_torch_stream())
     check(lib.vsom_bmu_cosine_x3_planes_dots(ptr(xplanes), ptr(wplanes), B, K, L, ptr(ws), ws.numel(), stream()),
           "vsom_bmu_cosine_x3_planes_dots")
     if rec is not None:
-        e1.record()
+        e1.record(_lib_mod.launch_torch_stream())
         rec.append((e0, e1))
     check(lib.vsom_bmu_cosine_x3_planes_finalize(ptr(x), _rows(x), ptr(W), ptr(xplanes), ptr(wplanes), ptr(ws), ws.numel(),
                                                  ptr(dist), ptr(bmu), ptr(inv_nx), ptr(inv_nw), ptr(reranked), B, K, L, stream()),
@@ -425,10 +426,10 @@ def bmu_cosine_fwd(x, W, inv_nx, inv_nw, dist: Optional[torch.Tensor], bmu):
     rec = _timers.get("bmu_cosine_dots")
     if rec is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
+        e0.record(_lib_mod.launch_torch_stream())
     check(lib.vsom_bmu_cosine_dots(ptr(x), _rows(x), ptr(W), B, K, L, ptr(ws), ws.numel(), stream()), "vsom_bmu_cosine_dots")
     if rec is not None:
-        e1.record()
+        e1.record(_lib_mod.launch_torch_stream())
         rec.append((e0, e1))
     check(lib.vsom_bmu_cosine_finalize(ptr(ws), ws.numel(), ptr(inv_nx), ptr(inv_nw), ptr(dist), ptr(bmu), B, K, L, stream()),
           "vsom_bmu_cosine_finalize")
