@@ -212,9 +212,10 @@ def test_stream_level_concurrency_is_bitwise_identical():
 
 def _run_switch_combinations(cfg, finals, hooks, ops, vit_som_amd):
     # (last column: the LayerNorm backwards' column reductions in one launch per exchange piece, or one launch each)
+    # and the BMU pass on the SOM stream under the decoder forward, or on the main chain)
     for side, split, nblk, fused, lnb in (("0", "0", None, True, True), ("1", "1", None, True, True), ("1", "0", None, False, False),
                                           ("0", "1", 2, True, False), ("1", "1", 1, False, True), ("1", "1", None, True, False)):
-        hooks.set(side_stream=side == "1", fwd_split=split == "1", fwd_split_blocks=nblk, ln_reduce_batched=lnb)
+        hooks.set(side_stream=side == "1", fwd_split=split == "1", fwd_split_blocks=nblk, ln_reduce_batched=lnb, bmu_overlap=lnb)
         ops.set_attention_fused(fused)
         torch.manual_seed(0)
         m = vit_som_amd.ViTSOM(copy.deepcopy(cfg), device=DEV)

@@ -16,7 +16,8 @@ class _Hooks:
     adamw_planes = False        # True: FusedAdamW writes the prototypes' plane image in its own pass (+27 us on the critical path);
                                 # False: the training forward re-splits them on the SOM stream under the encoder (hidden)
     ln_reduce_batched = True    # the LayerNorm backwards' dgamma / dbeta reductions in one launch per exchange piece instead of 30 (ops.LayerNormJobs)
-    bmu_overlap = True          # clustering mode: the BMU pass on the SOM stream under the decoder forward (model.py _run_forward)
+    bmu_overlap = False         # True: the BMU pass on the SOM stream under the decoder forward (model.py _run_forward): -0.02..-0.04 ms per
+                                # step, but the contraction then shares the chip (72 instead of 58-63 us per launch) -- off: it runs alone
     launch_tape = True          # train_step_fused / training_step re-issue the recorded launches of a step from C (model.py)
 
     def set(self, **kw):
