@@ -325,7 +325,7 @@ int vsom_som_weighted_loss(const float* dist, const float* weights, const float*
    F.normalize x 2 + matmul + argmin of som_layer.py:119-122, 83-89 in one pass over X and W:
    stage 1 = X W^T on the bf16 matrix cores from a two-piece round-to-nearest split (three products; |error of
    the normalised dot| <= 3 * 2^-16) + the squared row norms of X and W; stage 2 = inv_nx / inv_nw
-   (1 / max(|row|, 1e-12)), dist, and bmu = first argmin after every prototype within 1e-4 of the approximate
+   (1 / max(|row|, 1e-12)), dist, and bmu = first argmin after every prototype within 2e-4 of the approximate
    minimum has been re-ranked with an exact (fp64-accumulated) dot product, whose distance also replaces the
    approximate one in dist: bmu == argmin(dist) exactly.  K <= 2048; rows 16-byte aligned. */
 size_t vsom_bmu_cosine_x3_workspace_bytes(int B, int K, int L);
