@@ -223,9 +223,11 @@ static TnPlan bwd_weight_plan(int M, int N, int K) {
     }
     const int tiles = p.cfg == 1 ? (N / 192) * (K / 64) : (N / 96) * (K / 96);
     const int ktiles = cdiv(M, 32);
-    // two resident workgroups per CU (512): the kernel's own optimum.  Inside the step, where it shares the chip with the
-    // backward chain, 384 measured 0.02-0.06 ms per step better and 256 / 768 / 1024 worse -- not worth 10 us per launch alone
-    int s = (512 + tiles / 2) / tiles;
+    // 384 workgroups.  Alone the kernel is fastest with two resident workgroups per CU (512), but inside the step, where it
+    // shares the chip with the backward chain, fewer and longer reduction ranges win -- and more so since the gradient GEMMs
+    // run three products (round 3, lab builds A/B on one box: 768 / 512 / 384 / 320 / 256 / 192 workgroups ->
+    // +0.17 / 0 / -0.08...-0.10 / 0 / +0.15 / +0.45 ms per step; rounding the count to a multiple of 8: no difference)
+    int s = (384 + tiles / 2) / tiles;
     if (s > ktiles) s = ktiles;
     if (s < 1) s = 1;
     const int per = cdiv(ktiles, s);
