@@ -144,7 +144,10 @@ def secondary_kernels(ops, B, dev):
                           "hbm_GBps": round(4.0 * (T * 3 * E + T * E) / (t_att * 1e-3) / 1e9, 1)},
         "attention_bwd": {"shape": {"images": B, "heads": H, "tokens": N, "head_dim": E // H}, "ms": round(t_attb, 4),
                           "achieved_TFLOPs": round(attb_tf, 1), "peak_TFLOPs": F32_MFMA_PEAK_TFLOPS,
-                          "frac": round(attb_tf / F32_MFMA_PEAK_TFLOPS, 3), "peak_basis": "f32 MFMA (16x16x4); 10 B H N^2 hd FLOP",
+                          "frac": round(attb_tf / F32_MFMA_PEAK_TFLOPS, 3),
+                          "peak_basis": ("quoted against the f32 MFMA peak (16x16x4) for continuity; in this mode the seven products run on bf16 "
+                                         "MFMA from the two-piece split (matrix pipe busy ~4 of the ~62 us: the kernel is staging / VALU / latency "
+                                         "bound, DESIGN.md section 4); 10 B H N^2 hd FLOP") if grad3 else "f32 MFMA (16x16x4); 10 B H N^2 hd FLOP",
                           "hbm_GBps": round(4.0 * (2 * T * 3 * E + 2 * T * E) / (t_attb * 1e-3) / 1e9, 1)},
         "linear_qkv_bwd_weight": {"shape": [3 * E, E, T], "ms": round(t_dw, 4), "achieved_f32_equiv_TFLOPs": round(dw_tf, 1),
                                   "peak_TFLOPs": round(lin_peak * (2.0 if grad3 else 1.0), 1),

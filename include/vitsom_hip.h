@@ -162,8 +162,10 @@ int vsom_attention_bwd(const float* qkv, const float* out, const float* dout, co
  * from qkv and the lse the forward saved (the fused kernels never materialise them).  Visualisation path only. */
 int vsom_attention_probs(const float* qkv, const float* lse, float* probs, int B, int N, int H, int hd,
                          vsom_stream_t stream);
-/* test hook: 0 = run the short-sequence backward as two launches (dQ, then dK/dV) instead of the fused one;
-   results are bit-identical either way (the GPU suite checks) */
+/* test hook: 0 = run the short-sequence backward as two launches (dQ, then dK/dV), 1 = one launch whose phases share
+   the scores (default), 2 = one launch that recomputes them: bit-identical results (the GPU suite checks) -- except that
+   form 1, at hd = 64 in VSOM_GEMM_SPLIT_BF16_GRAD3 mode, forms its seven products on the bf16 matrix cores from the
+   two-piece split of the gradient GEMMs (gradients within 8e-6 relative of fp64); 3 = form 1 with fp32 products always */
 int vsom_set_attention_fused(int fused);
 
 /* ------------------------------------------------------------------ SOM layer */

@@ -201,22 +201,28 @@ def test_stream_level_concurrency_is_bitwise_identical():
     from vit_som_amd import ops
     from vit_som_amd.tuning import hooks
     cfg = make_config(3, 32, 4, 192, 4, 3, 96, 2, (12, 12), 0, 96)
-    finals = []
-    try:
-        _run_switch_combinations(cfg, finals, hooks, ops, vit_som_amd)
-    finally:
-        hooks.reset()
-        ops.set_attention_fused(True)
-    assert all(torch.equal(finals[0], f) for f in finals[1:])
+    # six products everywhere: the forms of the attention backward are bit-identical there (in the default mode the fused
+    # form runs its products on the two-piece split); then the default mode with the attention form fixed
+    for mode, flip_attention in ((ops.GEMM_SPLIT_BF16, True), (ops.GEMM_SPLIT_BF16_GRAD3, False)):
+        finals = []
+        prev = ops.get_gemm_mode()
+        ops.set_gemm_mode(mode)
+        try:
+            _run_switch_combinations(cfg, finals, hooks, ops, vit_som_amd, flip_attention)
+        finally:
+            hooks.reset()
+            ops.set_attention_fused(True)
+            ops.set_gemm_mode(prev)
+        assert all(torch.equal(finals[0], f) for f in finals[1:])
 
 
-def _run_switch_combinations(cfg, finals, hooks, ops, vit_som_amd):
+def _run_switch_combinations(cfg, finals, hooks, ops, vit_som_amd, flip_attention=True):
     # (last column: the LayerNorm backwards' column reductions in one launch per exchange piece, or one launch each)
     # and the BMU pass on the SOM stream under the decoder forward, or on the main chain)
     for side, split, nblk, fused, lnb in (("0", "0", None, True, True), ("1", "1", None, True, True), ("1", "0", None, False, False),
                                           ("0", "1", 2, True, False), ("1", "1", 1, False, True), ("1", "1", None, True, False)):
         hooks.set(side_stream=side == "1", fwd_split=split == "1", fwd_split_blocks=nblk, ln_reduce_batched=lnb, bmu_overlap=lnb)
-        ops.set_attention_fused(fused)
+        ops.set_attention_fused(fused if flip_attention else True)
         torch.manual_seed(0)
         m = vit_som_amd.ViTSOM(copy.deepcopy(cfg), device=DEV)
         m.set_schedule(5000, 500)

@@ -249,7 +249,9 @@ def attn_ref(qkv, B, N, H, hd):
 
 @pytest.mark.parametrize("B,N,H,hd", [(4, 65, 3, 64), (3, 17, 2, 8), (2, 37, 2, 2), (3, 5, 3, 4), (2, 65, 3, 32),
                                        (2, 197, 2, 8), (1, 257, 3, 64), (2, 16, 1, 16), (2, 33, 2, 3)])
-def test_attention(ops, B, N, H, hd):
+def test_attention(ops, gemm_mode, B, N, H, hd):
+    """Forward exact-f32 in every mode (3e-6 abs); backward 5e-6 relative, except that in the default mode the hd = 64
+    short-sequence backward runs its products on the two-piece bf16 split like the gradient GEMMs (measured 8e-6)."""
     E = H * hd
     qkv = rnd(B, N, 3 * E, seed=1)
     q64 = qkv.double().requires_grad_(True)
@@ -261,16 +263,17 @@ def test_attention(ops, B, N, H, hd):
     ref.backward(dout.double())
     dqkv = torch.full((B, N, 3 * E), float("nan"), device=DEV); delta = torch.empty(B, H, N, device=DEV)
     ops.attention_bwd(dev(qkv), out, dev(dout), lse, dqkv, delta, B, N, H, hd)
-    assert rel_err(dqkv.cpu(), q64.grad) < 5e-6
+    assert rel_err(dqkv.cpu(), q64.grad) < (GRAD3_TOL if gemm_mode == "grad3" and hd == 64 else 5e-6)
 
 
 @pytest.mark.parametrize("B,N,H,hd", [(4, 65, 3, 64), (3, 64, 2, 64), (2, 50, 3, 64), (3, 33, 2, 64), (2, 17, 1, 64), (2, 65, 3, 32),
                                        (2, 49, 2, 16), (2, 197, 2, 8)])
-def test_attention_backward_forms_give_the_same_bits(ops, B, N, H, hd):
+def test_attention_backward_forms_give_the_same_bits(ops, gemm_mode, B, N, H, hd):
     """The short-sequence backward exists as two launches (hook 0), as one launch whose dK/dV phase re-uses the P and dS
     blocks of the dQ phase (1, the default where the shape allows) and as one launch that recomputes them (2): same
     arithmetic in the same order, so the gradients must be identical bit for bit -- incl. a ragged last tile (N = 50)
-    and shapes on which the default falls back to the other forms."""
+    and shapes on which the default falls back to the other forms.  (In the default GEMM mode form 1 runs its products on
+    the two-piece bf16 split at hd = 64: equal to the others within that mode's tolerance, and still deterministic.)"""
     E = H * hd
     qkv, dout = dev(rnd(B, N, 3 * E, seed=11)), dev(rnd(B, N, E, seed=12))
     out = torch.empty(B, N, E, device=DEV); lse = torch.empty(B, H, N, device=DEV)
@@ -284,8 +287,17 @@ def test_attention_backward_forms_give_the_same_bits(ops, B, N, H, hd):
             got.append((dqkv, delta))
     finally:
         ops.set_attention_fused(1)
-    for dqkv, delta in got[1:]:
-        assert torch.equal(dqkv, got[0][0]) and torch.equal(delta, got[0][1])
+    split_form = gemm_mode == "grad3" and hd == 64 and N <= 65
+    for i, (dqkv, delta) in enumerate(got[1:], 1):
+        if split_form and i == 1:
+            assert rel_err(dqkv.cpu(), got[0][0].cpu().double()) < GRAD3_TOL and torch.equal(delta, got[0][1])
+        else:
+            assert torch.equal(dqkv, got[0][0]) and torch.equal(delta, got[0][1])
+    if split_form:                                   # the split form repeats bit for bit
+        ops.set_attention_fused(1)
+        again = torch.full((B, N, 3 * E), float("nan"), device=DEV)
+        ops.attention_bwd(qkv, out, dout, lse, again, torch.empty(B, H, N, device=DEV), B, N, H, hd)
+        assert torch.equal(again, got[1][0])
 
 
 def test_attention_large_scores(ops):

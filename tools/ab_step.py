@@ -11,7 +11,7 @@ from vit_som_amd.tuning import hooks
 
 def apply(key, v):
     if key == "attn_fused":
-        ops.set_attention_fused(bool(int(v)))
+        ops.set_attention_fused(int(v))
     elif key == "gemm_mode":                         # 0 f32 MFMA, 1 six products everywhere, 2 (default) three in the gradient GEMMs
         ops.set_gemm_mode(int(v))
     else:

@@ -39,8 +39,11 @@
 
 namespace vsom {
 
+int gemm_grad_products();          // gemm_f32.hip: 3 in VSOM_GEMM_SPLIT_BF16_GRAD3 mode
+
 // test / measurement hook (vsom_set_attention_fused): 0 keeps the short-sequence backward as two launches, 1 is the
-// default (one launch; scores shared between its phases where the shape allows), 2 one launch with recomputed scores
+// default (one launch; scores shared between its phases where the shape allows; at hd = 64 in the default GEMM mode its
+// products run on the two-piece bf16 split), 2 one launch with recomputed scores, 3 = 1 with fp32 products in every mode
 static std::atomic<int> g_attn_fused{1};
 
 // tools/attn_lab.hip builds this file with VSOM_ATTN_STAMPS: thread 0 of every workgroup records the 100 MHz
@@ -84,6 +87,71 @@ struct ACfg {
 
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// ---- two-piece bf16 form of the score products (hd = 64; the gradient-GEMM mode of gemm_f32.hip applied to the attention
+// backward).  An fp32 value is split round-to-nearest into hi + lo (the dropped rest <= 2^-17 relative), a product of two
+// fragments is lo*hi + hi*lo + hi*hi on v_mfma_f32_16x16x32_bf16: 6 matrix instructions of 16 cycles per score tile instead
+// of 16 of 32.  Reduction slot (lane group qp, j) of MFMA m is d = 32 m + 4 qp + j (j < 4) and d = 32 m + 16 + 4 qp + j - 4
+// (j >= 4) for BOTH operands -- the two float4 chunks 2 m and 2 m + 1 a lane loads anyway.
+typedef __attribute__((ext_vector_type(8))) __bf16 abf16x8;
+typedef __attribute__((ext_vector_type(2))) __bf16 abf16x2;
+struct SplitFrag { abf16x8 hi[2], lo[2]; };              // hd = 64: two 32-deep MFMAs
+__device__ __forceinline__ void split8(const float (&v)[8], abf16x8& hi, abf16x8& lo) {
+    unsigned h[4], l[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const abf16x2 a = {(__bf16)v[2 * e], (__bf16)v[2 * e + 1]};
+        const unsigned u = __builtin_bit_cast(unsigned, a);
+        const float r0 = v[2 * e] - __uint_as_float(u << 16), r1 = v[2 * e + 1] - __uint_as_float(u & 0xffff0000u);
+        const abf16x2 b = {(__bf16)r0, (__bf16)r1};
+        h[e] = u; l[e] = __builtin_bit_cast(unsigned, b);
+    }
+    typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+    hi = __builtin_bit_cast(abf16x8, (u32x4v){h[0], h[1], h[2], h[3]});
+    lo = __builtin_bit_cast(abf16x8, (u32x4v){l[0], l[1], l[2], l[3]});
+}
+// f[4 g + s] = element s of chunk g (load_frag's order)
+__device__ __forceinline__ void split_frag(const float (&f)[16], SplitFrag& o) {
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = f[8 * m + j];
+        split8(v, o.hi[m], o.lo[m]);
+    }
+}
+// o[dt][d = 16 dt + 4 q' + reg][own row] += sum over the 32 tokens of TWO tiles of Z[token][d] * p[token][own row]: the
+// accumulate-type product, two 16-token tiles per 32-deep MFMA (slot (qp, j): token 4 qp + j of tile a for j < 4, token
+// 4 qp + j - 4 of tile b for j >= 4, both operands alike); pa / pb = the lane's four values of the two tiles.
+__device__ __forceinline__ void accum_x3_pair(f32x4 (&o)[4], const float* Zlds, int rowa, int rowb, int r, int qp, f32x4 pa, f32x4 pb) {
+    const float pv[8] = {pa[0], pa[1], pa[2], pa[3], pb[0], pb[1], pb[2], pb[3]};
+    abf16x8 bh, bl;
+    split8(pv, bh, bl);
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+        float zv[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            zv[j] = Zlds[ACfg<64>::off(rowa + 4 * qp + j, 16 * dt + r)];
+            zv[4 + j] = Zlds[ACfg<64>::off(rowb + 4 * qp + j, 16 * dt + r)];
+        }
+        abf16x8 ah, al;
+        split8(zv, ah, al);
+        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, o[dt], 0, 0, 0);
+        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, o[dt], 0, 0, 0);
+        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, o[dt], 0, 0, 0);
+    }
+}
+__device__ __forceinline__ f32x4 score_x3(const SplitFrag& a, const SplitFrag& b) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.lo[m], b.hi[m], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.hi[m], b.lo[m], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.hi[m], b.hi[m], acc, 0, 0, 0);
+    }
+    return acc;
 }
 // Cross-lane reductions without the LDS crossbar (ds_bpermute: an LDS instruction and its latency per step; these
 // sit on the kernels' serial chains).  Over the 4 lane groups (l >> 4): v_permlane16_swap / v_permlane32_swap
@@ -970,7 +1038,7 @@ __global__ __launch_bounds__(512) void attn_bwd_fused_kernel(const float* __rest
 // accumulations only: 320 MFMAs per wave instead of 448, and no second exp pass.  Needs 2 x (16 tiles)(16 tiles + 4)
 // floats <= the K + V regions: hd = 64.  The values are the same bits as the recomputed ones (a product commutes and
 // the reduction order over the head dim is the same), so the result is bit-identical to the other forms.
-template <int HDP, bool EXTRA>
+template <int HDP, bool EXTRA, bool BF16X3 = false>
 __global__ __launch_bounds__(256) void attn_bwd_shared_kernel(const float* __restrict__ qkv, const float* __restrict__ out,
                                                               const float* __restrict__ dout, const float* __restrict__ lse,
                                                               float* __restrict__ dqkv, float* __restrict__ delta, int N,
@@ -1029,6 +1097,8 @@ __global__ __launch_bounds__(256) void attn_bwd_shared_kernel(const float* __res
         if (wave == 0 && lane == 0) { delta[srow0] = D0; Es[0] = D0; }
     }
     f32x4 pT[4], dsT[4];
+    SplitFrag qs, dos;
+    if constexpr (BF16X3 && HDP == 64) { split_frag(qf, qs); split_frag(dof, dos); }
     {
         const int query = own;
         const bool qok = ook;
@@ -1051,7 +1121,18 @@ __global__ __launch_bounds__(256) void attn_bwd_shared_kernel(const float* __res
         for (int t = 0; t < 4; ++t) {
             if (t < ntile) {
                 f32x4 sc, dp;
-                score_tile2<HDP>(Ks, tok<EXTRA>(t, 0), qf, Vs, tok<EXTRA>(t, 0), dof, r, qp, sc, dp);
+                if constexpr (BF16X3 && HDP == 64) {
+                    float kf[16], vf[16];
+                    load_frag_lds<HDP>(kf, Ks, tok<EXTRA>(t, 0) + r, qp);
+                    load_frag_lds<HDP>(vf, Vs, tok<EXTRA>(t, 0) + r, qp);
+                    SplitFrag ka, va;
+                    split_frag(kf, ka);
+                    split_frag(vf, va);
+                    sc = score_x3(ka, qs);
+                    dp = score_x3(va, dos);
+                } else {
+                    score_tile2<HDP>(Ks, tok<EXTRA>(t, 0), qf, Vs, tok<EXTRA>(t, 0), dof, r, qp, sc, dp);
+                }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int key = tok<EXTRA>(t, 4 * qp + e);
@@ -1059,7 +1140,13 @@ __global__ __launch_bounds__(256) void attn_bwd_shared_kernel(const float* __res
                     pT[t][e] = p;
                     dsT[t][e] = p * (dp[e] - D) * scale;
                 }
-                accum_tile<HDP>(dq, Ks, tok<EXTRA>(t, 0), r, qp, dsT[t]);
+                if constexpr (BF16X3 && HDP == 64) {
+                    // two tiles per 32-deep MFMA: a tile waits for its partner, an odd last tile takes the fp32 form
+                    if (t & 1) accum_x3_pair(dq, Ks, tok<EXTRA>(t - 1, 0), tok<EXTRA>(t, 0), r, qp, dsT[t - 1], dsT[t]);
+                    else if (t + 1 >= ntile) accum_tile<HDP>(dq, Ks, tok<EXTRA>(t, 0), r, qp, dsT[t]);
+                } else {
+                    accum_tile<HDP>(dq, Ks, tok<EXTRA>(t, 0), r, qp, dsT[t]);
+                }
             }
         }
         store_rows<HDP>(dq, dqkv + ((long)b * N + query) * E3 + h * hd, qp, qok, hd);
@@ -1109,6 +1196,20 @@ __global__ __launch_bounds__(256) void attn_bwd_shared_kernel(const float* __res
             for (int e = 0; e < 4; ++e) {
                 p[e] = Pm[(16 * t + 4 * qp + e) * PS + 16 * wave + r];
                 ds[e] = Dm[(16 * t + 4 * qp + e) * PS + 16 * wave + r];
+            }
+            if constexpr (BF16X3 && HDP == 64) {
+                if (t + 1 < ntile) {
+                    f32x4 p1, ds1;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        p1[e] = Pm[(16 * (t + 1) + 4 * qp + e) * PS + 16 * wave + r];
+                        ds1[e] = Dm[(16 * (t + 1) + 4 * qp + e) * PS + 16 * wave + r];
+                    }
+                    accum_x3_pair(dv, Ds, tok<EXTRA>(t, 0), tok<EXTRA>(t + 1, 0), r, qp, p, p1);
+                    accum_x3_pair(dk, Qs, tok<EXTRA>(t, 0), tok<EXTRA>(t + 1, 0), r, qp, ds, ds1);
+                    ++t;
+                    continue;
+                }
             }
             accum_tile2<HDP>(dv, Ds, p, dk, Qs, ds, tok<EXTRA>(t, 0), r, qp);
         }
@@ -1179,7 +1280,14 @@ static int launch_bwd_t(const float* qkv, const float* out, const float* dout, c
     if constexpr (ACfg<HDP>::VEC) {
         const int nt = attn_tiles(N), nrows = use_extra(N) ? N : nt * 16;
         const size_t shared_lds = fused_lds + 2 * HDP * sizeof(float);
-        if (mode == 1 && nt <= 4 && attn_waves(N) == nt && 16 * nt * (16 * nt + 4) <= nrows * (HDP + 4) && shared_lds <= 80 * 1024) {
+        if ((mode == 1 || mode == 3) && nt <= 4 && attn_waves(N) == nt && 16 * nt * (16 * nt + 4) <= nrows * (HDP + 4) && shared_lds <= 80 * 1024) {
+            if constexpr (HDP == 64) {
+                if (gemm_grad_products() == 3 && mode == 1) {   // the mode whose gradient GEMMs run on the two-piece split (hook 3: fp32 products)
+                    VSOM_LAUNCH((attn_bwd_shared_kernel<HDP, EXTRA, true>), dim3(B * H), block, shared_lds, st, qkv, out, dout, lse,
+                                dqkv, delta, N, H, hd, scale);
+                    VSOM_LAUNCH_CHECK("attn_bwd_shared_kernel");
+                }
+            }
             VSOM_LAUNCH((attn_bwd_shared_kernel<HDP, EXTRA>), dim3(B * H), block, shared_lds, st, qkv, out, dout, lse, dqkv,
                                delta, N, H, hd, scale);
             VSOM_LAUNCH_CHECK("attn_bwd_shared_kernel");
@@ -1246,7 +1354,7 @@ using namespace vsom;
 extern "C" {
 
 int vsom_set_attention_fused(int fused) {
-    g_attn_fused.store(fused < 0 ? 0 : (fused > 2 ? 2 : fused), std::memory_order_relaxed);
+    g_attn_fused.store(fused < 0 ? 0 : (fused > 3 ? 3 : fused), std::memory_order_relaxed);
     return VSOM_OK;
 }
 
