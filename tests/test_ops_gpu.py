@@ -290,7 +290,8 @@ def test_attention_backward_forms_give_the_same_bits(ops, gemm_mode, B, N, H, hd
     split_form = gemm_mode == "grad3" and hd == 64 and N <= 65
     for i, (dqkv, delta) in enumerate(got[1:], 1):
         if split_form and i == 1:
-            assert rel_err(dqkv.cpu(), got[0][0].cpu().double()) < GRAD3_TOL and torch.equal(delta, got[0][1])
+            # (the split form takes D = sum_j p_ij dP_ij from its own blocks instead of dO . O: same number, other rounding)
+            assert rel_err(dqkv.cpu(), got[0][0].cpu().double()) < GRAD3_TOL and rel_err(delta.cpu(), got[0][1].cpu().double()) < GRAD3_TOL
         else:
             assert torch.equal(dqkv, got[0][0]) and torch.equal(delta, got[0][1])
     if split_form:                                   # the split form repeats bit for bit

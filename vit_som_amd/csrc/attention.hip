@@ -1076,7 +1076,7 @@ __global__ __launch_bounds__(256) void attn_bwd_shared_kernel(const float* __res
     const bool ook = own < N;
     load_frag<HDP>(qf, base + (long)own * E3, qp, ook, hd);
     load_frag<HDP>(dof, dout + obase + (long)own * E, qp, ook, hd);
-    load_frag<HDP>(of, out + obase + (long)own * E, qp, ook, hd);
+    if constexpr (!(BF16X3 && HDP == 64)) load_frag<HDP>(of, out + obase + (long)own * E, qp, ook, hd);     // (the split form takes D from P and dP)
     float o0 = 0.f;
     if (EXTRA && lane < hd) o0 = out[obase + lane];
     float l_r = 0.f;
@@ -1102,49 +1102,78 @@ __global__ __launch_bounds__(256) void attn_bwd_shared_kernel(const float* __res
     {
         const int query = own;
         const bool qok = ook;
-        float D = 0.f;
-#pragma unroll
-        for (int mm = 0; mm < NMM; ++mm) D = fmaf(dof[mm], of[mm], D);
-        D = group_sum(D);
-        if (qp == 0 && qok) { delta[srow0 + query] = D; Es[query] = D; }
         const float lq = qok ? Ls[query] : 0.f;
         f32x4 dq[NDT];
 #pragma unroll
         for (int dt = 0; dt < NDT; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (EXTRA) {                                                   // token 0 as a key
-            const float s0 = frag_dot_row<HDP>(qf, Ks, qp) * scale;
-            const float dp0 = frag_dot_row<HDP>(dof, Vs, qp);
-            const float p0 = __expf(s0 - lq);
-            axpy_row<HDP>(dq, p0 * (dp0 - D) * scale, Ks, qp);
-        }
+        if constexpr (BF16X3 && HDP == 64) {
+            // D_i = dO_i . O_i = sum_j p_ij dP_ij: taken from the blocks the wave forms anyway, so the O rows are never read
+            // (an eighth of the kernel's HBM traffic).  All tiles' P and dP first, then D, then dS and the accumulation.
+            float s0 = 0.f, dp0 = 0.f, p0 = 0.f, dsum = 0.f;
+            if (EXTRA) {                                               // token 0 as a key
+                s0 = frag_dot_row<HDP>(qf, Ks, qp) * scale;
+                dp0 = frag_dot_row<HDP>(dof, Vs, qp);
+                p0 = __expf(s0 - lq);
+                if (qp == 0) dsum = p0 * dp0;                          // (the four lane groups hold the same p0, dp0: counted once)
+            }
+            f32x4 dpT[4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            if (t < ntile) {
-                f32x4 sc, dp;
-                if constexpr (BF16X3 && HDP == 64) {
+            for (int t = 0; t < 4; ++t) {
+                if (t < ntile) {
                     float kf[16], vf[16];
                     load_frag_lds<HDP>(kf, Ks, tok<EXTRA>(t, 0) + r, qp);
                     load_frag_lds<HDP>(vf, Vs, tok<EXTRA>(t, 0) + r, qp);
                     SplitFrag ka, va;
                     split_frag(kf, ka);
                     split_frag(vf, va);
-                    sc = score_x3(ka, qs);
-                    dp = score_x3(va, dos);
-                } else {
-                    score_tile2<HDP>(Ks, tok<EXTRA>(t, 0), qf, Vs, tok<EXTRA>(t, 0), dof, r, qp, sc, dp);
-                }
+                    const f32x4 sc = score_x3(ka, qs);
+                    dpT[t] = score_x3(va, dos);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int key = tok<EXTRA>(t, 4 * qp + e);
-                    const float p = (EXTRA || (key < N && qok)) ? __expf(sc[e] * scale - lq) : 0.f;
-                    pT[t][e] = p;
-                    dsT[t][e] = p * (dp[e] - D) * scale;
+                    for (int e = 0; e < 4; ++e) {
+                        const int key = tok<EXTRA>(t, 4 * qp + e);
+                        const float p = (EXTRA || (key < N && qok)) ? __expf(sc[e] * scale - lq) : 0.f;
+                        pT[t][e] = p;
+                        dsum = fmaf(p, dpT[t][e], dsum);
+                    }
                 }
-                if constexpr (BF16X3 && HDP == 64) {
+            }
+            const float D = group_sum(dsum);
+            if (qp == 0 && qok) { delta[srow0 + query] = D; Es[query] = D; }
+            if (EXTRA) axpy_row<HDP>(dq, p0 * (dp0 - D) * scale, Ks, qp);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                if (t < ntile) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) dsT[t][e] = pT[t][e] * (dpT[t][e] - D) * scale;
                     // two tiles per 32-deep MFMA: a tile waits for its partner, an odd last tile takes the fp32 form
                     if (t & 1) accum_x3_pair(dq, Ks, tok<EXTRA>(t - 1, 0), tok<EXTRA>(t, 0), r, qp, dsT[t - 1], dsT[t]);
                     else if (t + 1 >= ntile) accum_tile<HDP>(dq, Ks, tok<EXTRA>(t, 0), r, qp, dsT[t]);
-                } else {
+                }
+            }
+        } else {
+            float D = 0.f;
+#pragma unroll
+            for (int mm = 0; mm < NMM; ++mm) D = fmaf(dof[mm], of[mm], D);
+            D = group_sum(D);
+            if (qp == 0 && qok) { delta[srow0 + query] = D; Es[query] = D; }
+            if (EXTRA) {                                                   // token 0 as a key
+                const float s0 = frag_dot_row<HDP>(qf, Ks, qp) * scale;
+                const float dp0 = frag_dot_row<HDP>(dof, Vs, qp);
+                const float p0 = __expf(s0 - lq);
+                axpy_row<HDP>(dq, p0 * (dp0 - D) * scale, Ks, qp);
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                if (t < ntile) {
+                    f32x4 sc, dp;
+                    score_tile2<HDP>(Ks, tok<EXTRA>(t, 0), qf, Vs, tok<EXTRA>(t, 0), dof, r, qp, sc, dp);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int key = tok<EXTRA>(t, 4 * qp + e);
+                        const float p = (EXTRA || (key < N && qok)) ? __expf(sc[e] * scale - lq) : 0.f;
+                        pT[t][e] = p;
+                        dsT[t][e] = p * (dp[e] - D) * scale;
+                    }
                     accum_tile<HDP>(dq, Ks, tok<EXTRA>(t, 0), r, qp, dsT[t]);
                 }
             }
